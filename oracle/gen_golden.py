@@ -1,0 +1,258 @@
+"""TEST INFRASTRUCTURE (build container only). Generates tests/golden/*.npz by running the
+UNMODIFIED reference files (loaded by path, oracle/ref_loader.py) and the compiled reference
+RoIAlign (oracle/_ref) on seeded inputs.  Fixtures hold data only: inputs, parameters,
+expected outputs and gradients.  Run:  python oracle/gen_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import arfe_oracle as O            # noqa: E402  (only for the shared synthetic-input helpers)
+from oracle.ref_loader import load_reference   # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden')
+torch.set_num_threads(8)
+
+
+def npd(d):
+    out = {}
+    for k, v in d.items():
+        if v is None:      # a parameter/level no RoI touched: autograd leaves .grad None == zero gradient
+            src = d[k[1:]] if k[1:] in d else d[k.replace('dneck.', 'neck.').replace('dhead.', 'head.').replace('dp.', 'p.')]
+            v = torch.zeros_like(src)
+        out[k] = v.detach().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+    return out
+
+
+def randomise(module, gen, bias_scale=0.1):
+    """init_weights() zeroes every bias; give biases small random values so they are exercised."""
+    with torch.no_grad():
+        for n, p in module.named_parameters():
+            if n.endswith('bias'):
+                p.copy_(torch.randn(p.shape, generator=gen) * bias_scale)
+
+
+def arfpn_case(ns, name, channels, sizes, batch, refine_level, seed, scale_w=1.0):
+    gen = torch.Generator().manual_seed(seed)
+    torch.manual_seed(seed)
+    neck = ns.WFPNDualSpatial(channels, len(sizes), refine_level=refine_level)
+    neck.init_weights()
+    randomise(neck, gen)
+    if scale_w != 1.0:   # larger NonLocal weights -> a peaky softmax, exercises the online-softmax rescale
+        with torch.no_grad():
+            for n, p in neck.named_parameters():
+                if n.startswith('refine') and n.endswith('weight'):
+                    p.mul_(scale_w)
+    xs = [torch.randn(batch, channels, h, w, generator=gen, requires_grad=True) for h, w in sizes]
+    cots = [torch.randn(batch, channels, h, w, generator=gen) for h, w in sizes]
+    outs = neck(xs)
+    loss = sum((o * c).sum() for o, c in zip(outs, cots))
+    loss.backward()
+    d = {'refine_level': refine_level}
+    for i in range(len(sizes)):
+        d[f'x{i}'] = xs[i]
+        d[f'cot{i}'] = cots[i]
+        d[f'out{i}'] = outs[i]
+        d[f'dx{i}'] = xs[i].grad
+    for n, p in neck.named_parameters():
+        d['p.' + n] = p
+        d['dp.' + n] = p.grad
+    np.savez_compressed(os.path.join(OUT, name), **npd(d))
+    print(name, 'ok')
+
+
+def checksum(t):
+    t = t.detach().double()
+    flat = t.flatten()
+    idx = (torch.arange(64, dtype=torch.int64) * (flat.numel() - 1)) // 63
+    return dict(sum=t.sum().item(), abssum=t.abs().sum().item(), samples=flat[idx].numpy(), idx=idx.numpy())
+
+
+def arfpn_full(ns, name, refine_level):
+    """Full BASELINE size (B=1, 256 ch, 1333x800 pyramid): checksums + strided samples only."""
+    p = O.arfpn_params(256, 5, seed=11)
+    neck = ns.WFPNDualSpatial(256, 5, refine_level=refine_level)
+    neck.load_state_dict(p)
+    xs = [x.requires_grad_(True) for x in O.synth_pyramid(1, 256, seed=1234)]
+    cots = O.synth_pyramid(1, 256, seed=4321)
+    outs = neck(xs)
+    sum((o * c).sum() for o, c in zip(outs, cots)).backward()
+    d = {}
+    for i in range(5):
+        for k, v in checksum(outs[i]).items():
+            d[f'out{i}.{k}'] = v
+        for k, v in checksum(xs[i].grad).items():
+            d[f'dx{i}.{k}'] = v
+    for n, q in neck.named_parameters():
+        for k, v in checksum(q.grad).items():
+            d[f'dp.{n}.{k}'] = v
+    np.savez_compressed(os.path.join(OUT, name), **d)
+    print(name, 'ok')
+
+
+def rois_cases(ns):
+    gen = torch.Generator().manual_seed(5)
+    r = O.synth_rois(2, 300, seed=99)
+    special = torch.tensor([
+        [0, 0., 0., 0., 0.],            # degenerate point at the origin
+        [0, 0., 0., 15., 7.],           # at the border (x1/y1 clamp to 0.1)
+        [1, 1343., 799., 1343., 799.],  # degenerate at the far corner
+        [1, 10., 20., 10., 300.],       # zero width
+        [0, 5., 5., 1300., 30.],        # extreme aspect
+        [0, 100.5, 200.25, 163.75, 420.125],
+    ])
+    rois = torch.cat([special, r], 0)
+    h, w = ns.get_adaptive_scale_rois(rois, 1)
+    np.savez_compressed(os.path.join(OUT, 'rois_make.npz'), rois=rois.numpy(), h_rois=h.numpy(), w_rois=w.numpy())
+
+    # level mapping: dense sweep of box sizes whose sqrt-area sits within +-64 ulp of every step
+    class E:
+        finest_scale = 56
+    sides = []
+    for thr in (112.0, 224.0, 448.0, 896.0):
+        v = np.float32(thr)
+        lo = v
+        for _ in range(200):
+            lo = np.nextafter(lo, np.float32(0))
+        cur = lo
+        for _ in range(400):
+            sides.append(cur)
+            cur = np.nextafter(cur, np.float32(1e9))
+    sides = np.array(sides, dtype=np.float32)
+    sq = np.stack([np.zeros_like(sides), np.zeros_like(sides), np.zeros_like(sides), sides, sides], 1)
+    # non-square boxes with the same nominal area, random aspect
+    asp = np.exp(np.random.RandomState(3).uniform(-1.5, 1.5, sides.shape)).astype(np.float32)
+    ns_w = (sides * asp).astype(np.float32)
+    ns_h = (sides / asp).astype(np.float32)
+    rect = np.stack([np.zeros_like(sides), np.full_like(sides, 7.25), np.full_like(sides, 3.5),
+                     (7.25 + ns_w).astype(np.float32), (3.5 + ns_h).astype(np.float32)], 1)
+    allr = torch.from_numpy(np.concatenate([sq, rect, rois.numpy()], 0))
+    lv = ns.SingleRoIExtractor.map_roi_levels(E, allr, 5)
+    lv4 = ns.SingleRoIExtractor.map_roi_levels(E, allr, 4)
+    np.savez_compressed(os.path.join(OUT, 'roi_levels.npz'), rois=allr.numpy(), levels5=lv.numpy(), levels4=lv4.numpy())
+    print('rois ok', np.bincount(lv.numpy()))
+
+
+def roialign_case(ns):
+    gen = torch.Generator().manual_seed(21)
+    C = 6
+    sizes = ((40, 64), (20, 32), (10, 16), (5, 8), (3, 4))   # 160x256 image, strides 4..64
+    feats = [torch.randn(2, C, h, w, generator=gen, requires_grad=True) for h, w in sizes]
+    n = 40
+    x1 = torch.rand(n, generator=gen) * 200
+    y1 = torch.rand(n, generator=gen) * 120
+    w = torch.exp(torch.rand(n, generator=gen) * 4.0 + 1.0)
+    h = torch.exp(torch.rand(n, generator=gen) * 4.0 + 1.0)
+    rois = torch.stack([(torch.arange(n) % 2).float(), x1, y1, x1 + w, y1 + h], 1)
+    rois = torch.cat([rois, torch.tensor([[0, -20., -30., 40., 50.],     # partly outside (negative)
+                                          [1, 200., 100., 400., 300.],  # partly outside (beyond)
+                                          [0, 17., 23., 17., 23.],      # zero size -> grid 0 -> zeros
+                                          [1, 0.1, 0.1, 255., 159.]])], 0)
+    ext = ns.SingleRoIExtractor(dict(type='RoIAlign', out_size=7, sample_num=0), C, [4, 8, 16, 32, 64])
+    h_r, w_r = ns.get_adaptive_scale_rois(rois, 1)
+    ori = ext(feats, rois)
+    fw = ext(feats, w_r)
+    fh = ext(feats, h_r)
+    cat = torch.cat([ori, fw, fh], dim=1)
+    cot = torch.randn(cat.shape, generator=gen)
+    (cat * cot).sum().backward()
+    d = dict(rois=rois, cat=cat, cot=cot)
+    for i in range(5):
+        d[f'feat{i}'] = feats[i]
+        d[f'dfeat{i}'] = feats[i].grad if feats[i].grad is not None else torch.zeros_like(feats[i])
+    # single-level, fixed sample_num variant straight from the compiled reference
+    f0 = feats[1].detach()
+    o2 = ns.roi_align_ext.forward_v2(f0, rois, 1.0 / 8, 7, 7, 2, True)
+    d['single_lvl1_sn2'] = o2
+    np.savez_compressed(os.path.join(OUT, 'roialign.npz'), **npd(d))
+    print('roialign ok')
+
+
+def head_case(ns, name, C, fc, R, seed):
+    gen = torch.Generator().manual_seed(seed)
+    torch.manual_seed(seed)
+    head = ns.MultiRoIsBBoxHead(in_channels=C, conv_out_channels=C, fc_out_channels=fc, roi_feat_size=7,
+                                num_classes=80)
+    head.init_weights()
+    randomise(head, gen)
+    x = torch.randn(R, 3 * C, 7, 7, generator=gen, requires_grad=True)
+    cls, reg = head(x)
+    c1 = torch.randn(cls.shape, generator=gen)
+    c2 = torch.randn(reg.shape, generator=gen)
+    ((cls * c1).sum() + (reg * c2).sum()).backward()
+    d = dict(x=x, cls=cls, reg=reg, cot_cls=c1, cot_reg=c2, dx=x.grad)
+    for n, p in head.named_parameters():
+        d['p.' + n] = p
+        d['dp.' + n] = p.grad
+    np.savez_compressed(os.path.join(OUT, name), **npd(d))
+    print(name, 'ok')
+
+
+def e2e_case(ns):
+    """neck -> [ori | w | h] RoIAlign concat (the intended, disabled glue of standard_roi_head.py:138-155,
+    restated in 6 lines here) -> MultiRoIsBBoxHead; grads w.r.t. the pyramid and every parameter."""
+    gen = torch.Generator().manual_seed(77)
+    torch.manual_seed(77)
+    C = 8
+    sizes = ((40, 64), (20, 32), (10, 16), (5, 8), (3, 4))
+    neck = ns.WFPNDualSpatial(C, 5)
+    neck.init_weights()
+    randomise(neck, gen)
+    head = ns.MultiRoIsBBoxHead(in_channels=C, conv_out_channels=C, fc_out_channels=24, roi_feat_size=7,
+                                num_classes=80)
+    head.init_weights()
+    randomise(head, gen)
+    ext = ns.SingleRoIExtractor(dict(type='RoIAlign', out_size=7, sample_num=0), C, [4, 8, 16, 32, 64])
+    xs = [torch.randn(2, C, h, w, generator=gen, requires_grad=True) for h, w in sizes]
+    n = 24
+    x1 = torch.rand(n, generator=gen) * 180
+    y1 = torch.rand(n, generator=gen) * 100
+    w = torch.exp(torch.rand(n, generator=gen) * 3.5 + 1.5)
+    h = torch.exp(torch.rand(n, generator=gen) * 3.5 + 1.5)
+    rois = torch.stack([(torch.arange(n) // 12).float(), x1, y1, x1 + w, y1 + h], 1)
+    feats = neck(xs)
+    lh_rois, lw_rois = ns.get_adaptive_scale_rois(rois, 1)
+    bbox_feats = torch.cat([ext(feats, rois), ext(feats, lw_rois), ext(feats, lh_rois)], dim=1)
+    cls, reg = head(bbox_feats)
+    c1 = torch.randn(cls.shape, generator=gen)
+    c2 = torch.randn(reg.shape, generator=gen)
+    ((cls * c1).sum() + (reg * c2).sum()).backward()
+    d = dict(rois=rois, cls=cls, reg=reg, cot_cls=c1, cot_reg=c2, bbox_feats=bbox_feats)
+    for i in range(5):
+        d[f'x{i}'] = xs[i]
+        d[f'dx{i}'] = xs[i].grad
+        d[f'feat{i}'] = feats[i]
+    for n_, p in neck.named_parameters():
+        d['neck.' + n_] = p
+        d['dneck.' + n_] = p.grad
+    for n_, p in head.named_parameters():
+        d['head.' + n_] = p
+        d['dhead.' + n_] = p.grad
+    np.savez_compressed(os.path.join(OUT, 'e2e_small.npz'), **npd(d))
+    print('e2e ok')
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ns = load_reference()
+    assert ns.RoIAlign is not None, "run oracle/build_ref.py first"
+    tiny = ((16, 24), (8, 12), (4, 6), (2, 3), (1, 2))
+    ragged = ((40, 67), (20, 34), (10, 17), (5, 9), (3, 5))
+    arfpn_case(ns, 'arfpn_tiny_r2.npz', 8, tiny, 2, 2, seed=1)
+    arfpn_case(ns, 'arfpn_tiny_r3.npz', 8, tiny, 2, 3, seed=2)
+    arfpn_case(ns, 'arfpn_ragged_r2.npz', 8, ragged, 1, 2, seed=3)
+    arfpn_case(ns, 'arfpn_ragged_r3.npz', 8, ragged, 2, 3, seed=4)
+    arfpn_case(ns, 'arfpn_peaky_r2.npz', 16, ragged, 1, 2, seed=5, scale_w=6.0)
+    arfpn_full(ns, 'arfpn_full_r2_checksum.npz', 2)
+    rois_cases(ns)
+    roialign_case(ns)
+    head_case(ns, 'rff_head_r8.npz', 16, 32, 8, seed=6)
+    head_case(ns, 'rff_head_r40.npz', 8, 24, 40, seed=7)
+    e2e_case(ns)
+
+
+if __name__ == '__main__':
+    main()

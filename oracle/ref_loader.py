@@ -1,0 +1,207 @@
+"""TEST INFRASTRUCTURE (container-only). Loads the *unmodified* reference hot-path
+files from /root/reference by path so golden vectors can be generated from them.
+
+The reference (a vendored mmdetection 2.0.0 fork) cannot be imported as a package:
+its third-party dependency `mmcv` (version unpinned, API of 0.5.x/0.6.x) is absent and
+there is no network.  The few symbols the hot-path files need from mmcv / mmdet are
+provided here as in-memory stand-ins whose semantics are restated from the call sites:
+
+  * mmcv.cnn.ConvModule(cin, cout, k, padding=p, act_cfg=<default ReLU>|None, ...)
+      == nn.Conv2d(bias=True) -> optional ReLU, parameters named `<name>.conv.weight/bias`
+      (evidence: callers wanting no activation pass act_cfg=None explicitly,
+      mmdet/ops/non_local.py:39-51).
+  * mmcv.cnn.xavier_init / normal_init / constant_init: thin wrappers over torch.nn.init.
+  * mmcv.utils.Registry / build_from_cfg: name -> class table.
+
+Parity at the mmcv boundary is therefore "unpinned" (no reference test pins ConvModule);
+everything downstream of that boundary is the reference's own code, executed as is.
+
+Nothing in this file is shipped to the GPU box's product path; it is never imported by
+`arfe_amd`.  /root/reference does not exist on the GPU box.
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import torch
+import torch.nn as nn
+
+REF_ROOT = os.environ.get("ARFE_REFERENCE_ROOT", "/root/reference")
+
+
+def reference_available():
+    return os.path.isdir(os.path.join(REF_ROOT, "mmdet"))
+
+
+# ----------------------------------------------------------------------------- mmcv stand-in
+class _ConvModule(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0,
+                 dilation=1, groups=1, bias='auto', conv_cfg=None, norm_cfg=None,
+                 act_cfg=dict(type='ReLU'), inplace=True, **kwargs):
+        super().__init__()
+        assert conv_cfg is None and norm_cfg is None, "hot path uses plain conv, no norm"
+        self.with_activation = act_cfg is not None
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride=stride,
+                              padding=padding, dilation=dilation, groups=groups,
+                              bias=True if bias == 'auto' else bias)
+        if self.with_activation:
+            assert act_cfg['type'] == 'ReLU'
+            self.activate = nn.ReLU(inplace=inplace)
+        nn.init.kaiming_normal_(self.conv.weight, a=0, mode='fan_out', nonlinearity='relu')
+        nn.init.constant_(self.conv.bias, 0)
+
+    def forward(self, x):
+        x = self.conv(x)
+        if self.with_activation:
+            x = self.activate(x)
+        return x
+
+
+def _xavier_init(module, gain=1, bias=0, distribution='normal'):
+    if distribution == 'uniform':
+        nn.init.xavier_uniform_(module.weight, gain=gain)
+    else:
+        nn.init.xavier_normal_(module.weight, gain=gain)
+    if getattr(module, 'bias', None) is not None:
+        nn.init.constant_(module.bias, bias)
+
+
+def _normal_init(module, mean=0, std=1, bias=0):
+    nn.init.normal_(module.weight, mean, std)
+    if getattr(module, 'bias', None) is not None:
+        nn.init.constant_(module.bias, bias)
+
+
+def _constant_init(module, val, bias=0):
+    nn.init.constant_(module.weight, val)
+    if getattr(module, 'bias', None) is not None:
+        nn.init.constant_(module.bias, bias)
+
+
+class _Registry:
+    def __init__(self, name):
+        self.name = name
+        self.module_dict = {}
+
+    def get(self, key):
+        return self.module_dict.get(key)
+
+    def register_module(self, cls=None, **kw):
+        if cls is None:
+            return lambda c: self.register_module(c)
+        self.module_dict[cls.__name__] = cls
+        return cls
+
+
+def _build_from_cfg(cfg, registry, default_args=None):
+    args = dict(cfg)
+    if default_args:
+        for k, v in default_args.items():
+            args.setdefault(k, v)
+    return registry.get(args.pop('type'))(**args)
+
+
+def _identity_decorator(*a, **k):
+    def deco(f):
+        return f
+    return deco
+
+
+_loaded = {}
+
+
+def _mod(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    m.__path__ = []  # behave as a package
+    sys.modules[name] = m
+    return m
+
+
+def _install_stubs():
+    if 'mmcv' in sys.modules and getattr(sys.modules['mmcv'], '_arfe_stub', False):
+        return
+    _mod('mmcv', _arfe_stub=True)
+    _mod('mmcv.cnn', ConvModule=_ConvModule, xavier_init=_xavier_init,
+         normal_init=_normal_init, constant_init=_constant_init)
+    _mod('mmcv.utils', Registry=_Registry, build_from_cfg=_build_from_cfg)
+    _mod('mmdet')
+    _mod('mmdet.ops')
+    _mod('mmdet.core', auto_fp16=_identity_decorator, force_fp32=_identity_decorator,
+         build_bbox_coder=lambda cfg: None, multi_apply=None, multiclass_nms=None)
+    _mod('mmdet.models')
+    _mod('mmdet.models.losses', accuracy=None)
+    _mod('mmdet.models.necks')
+    _mod('mmdet.models.utils')
+    _mod('mmdet.models.roi_heads')
+    _mod('mmdet.models.roi_heads.bbox_heads')
+    _mod('mmdet.models.roi_heads.roi_extractors')
+    reg = {n: _Registry(n) for n in
+           ('BACKBONES', 'NECKS', 'ROI_EXTRACTORS', 'SHARED_HEADS', 'HEADS', 'LOSSES', 'DETECTORS')}
+    _mod('mmdet.models.builder', build_loss=lambda cfg: None, **reg)
+
+
+def _load(modname, relpath):
+    if modname in _loaded:
+        return _loaded[modname]
+    path = os.path.join(REF_ROOT, relpath)
+    spec = importlib.util.spec_from_file_location(modname, path)
+    m = importlib.util.module_from_spec(spec)
+    sys.modules[modname] = m
+    spec.loader.exec_module(m)
+    _loaded[modname] = m
+    return m
+
+
+def load_reference():
+    """Returns a namespace with the reference classes/functions of the hot path."""
+    assert reference_available(), f"{REF_ROOT} not present (expected on the GPU box)"
+    _install_stubs()
+    nl = _load('mmdet.ops.non_local', 'mmdet/ops/non_local.py')
+    sys.modules['mmdet.ops'].NonLocal2D = nl.NonLocal2D
+    neck = _load('mmdet.models.necks.wfpn_dual_spatial', 'mmdet/models/necks/wfpn_dual_spatial.py')
+    add = _load('mmdet.models.utils.additional', 'mmdet/models/utils/additional.py')
+    sys.modules['mmdet'].ops = sys.modules['mmdet.ops']
+    bh = _load('mmdet.models.roi_heads.bbox_heads.bbox_head',
+               'mmdet/models/roi_heads/bbox_heads/bbox_head.py')
+    mh = _load('mmdet.models.roi_heads.bbox_heads.multirois_bbox_head',
+               'mmdet/models/roi_heads/bbox_heads/multirois_bbox_head.py')
+    ext = _load('mmdet.models.roi_heads.roi_extractors.single_level',
+                'mmdet/models/roi_heads/roi_extractors/single_level.py')
+    # the reference's python RoIAlign wrapper on top of the compiled reference sources (oracle/_ref)
+    RoIAlign = None
+    ext_mod = load_reference_roi_align()
+    if ext_mod is not None:
+        pkg = _mod('mmdet.ops.roi_align', roi_align_ext=ext_mod)
+        ra = _load('mmdet.ops.roi_align.roi_align', 'mmdet/ops/roi_align/roi_align.py')
+        pkg.RoIAlign = ra.RoIAlign
+        sys.modules['mmdet.ops'].RoIAlign = ra.RoIAlign
+        sys.modules['mmdet'].ops = sys.modules['mmdet.ops']
+        RoIAlign = ra.RoIAlign
+    ns = types.SimpleNamespace(
+        RoIAlign=RoIAlign,
+        roi_align_ext=ext_mod,
+        NonLocal2D=nl.NonLocal2D,
+        WFPNDualSpatial=neck.WFPNDualSpatial,
+        get_adaptive_scale_rois=add.get_adaptive_scale_rois,
+        BBoxHead=bh.BBoxHead,
+        MultiBBoxHead=mh.MultiBBoxHead,
+        MultiRoIsBBoxHead=mh.MultiRoIsBBoxHead,
+        SingleRoIExtractor=ext.SingleRoIExtractor,
+    )
+    return ns
+
+
+def load_reference_roi_align():
+    """The compiled reference RoIAlign (oracle/_ref, built by oracle/build_ref.py)."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    d = os.path.join(here, '_ref')
+    cands = [f for f in os.listdir(d)] if os.path.isdir(d) else []
+    so = [f for f in cands if f.startswith('arfe_ref_roi_align') and f.endswith('.so')]
+    if not so:
+        return None
+    spec = importlib.util.spec_from_file_location('arfe_ref_roi_align', os.path.join(d, so[0]))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
