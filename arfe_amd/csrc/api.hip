@@ -1,0 +1,42 @@
+// C-ABI plumbing: error strings, version, argument validation shared by all entry points.
+#include <stdarg.h>
+
+#include "common.hpp"
+
+namespace arfe {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int32_t check_pyramid(const arfe_pyramid_t* p) {
+    if (!p) { set_error("pyramid descriptor is null"); return ARFE_ERR_ARG; }
+    if (p->num_levels < 1 || p->num_levels > ARFE_MAX_LEVELS) {
+        set_error("num_levels=%d outside [1,%d]", p->num_levels, ARFE_MAX_LEVELS);
+        return ARFE_ERR_ARG;
+    }
+    if (p->refine_level < 0 || p->refine_level >= p->num_levels) {
+        set_error("refine_level=%d outside [0,%d)", p->refine_level, p->num_levels);
+        return ARFE_ERR_ARG;
+    }
+    if (p->batch < 1 || p->channels < 1) {
+        set_error("batch=%d channels=%d must be positive", p->batch, p->channels);
+        return ARFE_ERR_ARG;
+    }
+    for (int i = 0; i < p->num_levels; ++i)
+        if (p->height[i] < 1 || p->width[i] < 1) {
+            set_error("level %d has empty size %dx%d", i, p->height[i], p->width[i]);
+            return ARFE_ERR_ARG;
+        }
+    return ARFE_OK;
+}
+
+}  // namespace arfe
+
+extern "C" const char* arfe_last_error(void) { return arfe::g_err; }
+extern "C" int32_t arfe_abi_version(void) { return ARFE_ABI_VERSION; }

@@ -1,0 +1,100 @@
+// Shared helpers for the libarfe_hip kernels (gfx950 / MI355X only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/arfe_hip.h"
+
+namespace arfe {
+
+// ---- error plumbing (no exceptions cross the C ABI) -------------------------------------
+void set_error(const char* fmt, ...);
+
+#define ARFE_CHECK_ARG(cond, code, ...)        \
+    do {                                       \
+        if (!(cond)) {                         \
+            ::arfe::set_error(__VA_ARGS__);    \
+            return (code);                     \
+        }                                      \
+    } while (0)
+
+#define ARFE_CHECK_LAUNCH()                                                   \
+    do {                                                                      \
+        hipError_t e__ = hipGetLastError();                                   \
+        if (e__ != hipSuccess) {                                              \
+            ::arfe::set_error("%s:%d launch failed: %s", __FILE__, __LINE__,  \
+                              hipGetErrorString(e__));                        \
+            return ARFE_ERR_LAUNCH;                                           \
+        }                                                                     \
+    } while (0)
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- index semantics shared by the AR-FPN kernels -----------------
+// PyTorch legacy 'nearest': src = min((int)floorf(dst * scale), in-1), scale = (float)in/out in fp32.
+__device__ __forceinline__ int nearest_src(int dst, int in_size, float scale) {
+    int s = (int)floorf((float)dst * scale);
+    return s < in_size - 1 ? s : in_size - 1;
+}
+__host__ __device__ __forceinline__ float nearest_scale(int in_size, int out_size) {
+    return (float)in_size / (float)out_size;
+}
+// first dst index d in [0,out] with nearest_src(d) >= s  (the map is monotone non-decreasing)
+__device__ __forceinline__ int nearest_dst_begin(int s, int in_size, int out_size, float scale) {
+    if (s <= 0) return 0;
+    if (s > in_size - 1) return out_size;
+    int d = (int)ceilf((float)s / scale);
+    if (d > out_size) d = out_size;
+    if (d < 0) d = 0;
+    while (d > 0 && nearest_src(d - 1, in_size, scale) >= s) --d;
+    while (d < out_size && nearest_src(d, in_size, scale) < s) ++d;
+    return d;
+}
+// adaptive max pool window of output index o: [floor(o*in/out), ceil((o+1)*in/out))
+__device__ __forceinline__ int pool_start(int o, int in_size, int out_size) {
+    return (int)(((int64_t)o * in_size) / out_size);
+}
+__device__ __forceinline__ int pool_end(int o, int in_size, int out_size) {
+    return (int)((((int64_t)(o + 1)) * in_size + out_size - 1) / out_size);
+}
+
+// ---- wave-level reductions (wave = 64 lanes) --------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// 16-byte vector with only 4-byte alignment promised (rows of odd width are not 16-B aligned;
+// the hardware runs in unaligned-access mode, the type keeps the compiler honest).
+typedef float float4_u __attribute__((ext_vector_type(4), aligned(4)));
+
+struct Levels {
+    int n;        // number of pyramid levels
+    int r;        // refine level
+    int B, C;
+    int H[ARFE_MAX_LEVELS], W[ARFE_MAX_LEVELS];
+};
+static inline Levels to_levels(const arfe_pyramid_t* p) {
+    Levels l;
+    l.n = p->num_levels; l.r = p->refine_level; l.B = p->batch; l.C = p->channels;
+    for (int i = 0; i < ARFE_MAX_LEVELS; ++i) { l.H[i] = p->height[i]; l.W[i] = p->width[i]; }
+    return l;
+}
+int32_t check_pyramid(const arfe_pyramid_t* p);
+
+template <int N>
+struct PtrArray { const float* p[N]; };
+template <int N>
+struct MutPtrArray { float* p[N]; };
+
+}  // namespace arfe

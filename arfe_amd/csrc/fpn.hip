@@ -1,0 +1,688 @@
+// AR-FPN (WFPNDualSpatial) streaming stages on gfx950: gather, gate maps, scatter+gate+residual and their
+// backward passes.  All of these are HBM-bound: one pyramid copy is 91.7 MB / image.
+//   layout: every level NCHW fp32, contiguous; lanes run along W so that a wave touches whole 128-B lines.
+#include "common.hpp"
+
+namespace arfe {
+
+constexpr int NL_ = ARFE_MAX_LEVELS;
+
+struct LevelPtrs { const float* p[NL_]; };
+struct LevelMutPtrs { float* p[NL_]; };
+
+// =========================================================================================================
+// gather:  m[b,c,py,px] = (sum_i G_i) / n ; one thread per refine-level element, lanes along px
+// =========================================================================================================
+__global__ __launch_bounds__(256) void fpn_gather_fwd_kernel(Levels lv, LevelPtrs x, float* __restrict__ m,
+                                                             int32_t* __restrict__ argmax) {
+    const int hr = lv.H[lv.r], wr = lv.W[lv.r];
+    const int64_t total = (int64_t)lv.B * lv.C * hr * wr;
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int px = (int)(idx % wr);
+    const int py = (int)((idx / wr) % hr);
+    const int64_t bc = idx / ((int64_t)wr * hr);
+    float acc = 0.f;
+    for (int i = 0; i < lv.n; ++i) {
+        const int h = lv.H[i], w = lv.W[i];
+        const float* plane = x.p[i] + bc * (int64_t)h * w;
+        float g;
+        if (i < lv.r) {
+            const int ys = pool_start(py, h, hr), ye = pool_end(py, h, hr);
+            const int xs = pool_start(px, w, wr), xe = pool_end(px, w, wr);
+            float mx = -INFINITY;
+            int am = ys * w + xs;
+            if (xe - xs == 4) {
+                for (int yy = ys; yy < ye; ++yy) {
+                    float4_u v = *reinterpret_cast<const float4_u*>(plane + (int64_t)yy * w + xs);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        float e = v[t];
+                        if (e > mx || e != e) { mx = e; am = yy * w + xs + t; }
+                    }
+                }
+            } else {
+                for (int yy = ys; yy < ye; ++yy)
+                    for (int xx = xs; xx < xe; ++xx) {
+                        float e = plane[(int64_t)yy * w + xx];
+                        if (e > mx || e != e) { mx = e; am = yy * w + xx; }
+                    }
+            }
+            g = mx;
+            if (argmax) argmax[(int64_t)i * total + idx] = am;
+        } else {
+            const int sy = nearest_src(py, h, nearest_scale(h, hr));
+            const int sx = nearest_src(px, w, nearest_scale(w, wr));
+            g = plane[(int64_t)sy * w + sx];
+        }
+        acc = acc + g;
+    }
+    m[idx] = acc / (float)lv.n;
+}
+
+// =========================================================================================================
+// gate maps: partial 3x3 conv sums over a channel group, LDS-tiled.
+//   tile = 16 x 64 output pixels, 256 threads x 4 px, channel chunk of 8 staged through LDS with its halo
+//   (interior columns at float index 4..67 so the interior read is one aligned ds_read_b128).
+//   grid.x = spatial tiles of all levels, grid.y = channel group; partial pre-activations go to
+//   pre[group][2][pixel] and are finished (bias, ReLU, tanh) by gate_finish_kernel.
+// =========================================================================================================
+constexpr int GT_H = 16, GT_W = 64, GT_CC = 8, GT_LD = 72;
+constexpr int GATE_GROUPS = 4;
+
+struct TileTable {
+    int first_tile[NL_ + 1];   // prefix sum of tiles per level
+    int tiles_x[NL_], tiles_y[NL_];
+    int64_t px_off[NL_ + 1];   // prefix sum of B*h*w (offset of a level inside a flattened per-pixel buffer)
+};
+
+__global__ __launch_bounds__(256) void fpn_gate_partial_kernel(Levels lv, TileTable tt, LevelPtrs x, LevelPtrs w1,
+                                                               LevelPtrs w2, float* __restrict__ pre, int64_t pre_total) {
+    __shared__ __attribute__((aligned(16))) float tile[GT_CC][GT_H + 2][GT_LD];
+    int t = blockIdx.x, lvl = 0;
+    while (lvl + 1 < lv.n && t >= tt.first_tile[lvl + 1]) ++lvl;
+    t -= tt.first_tile[lvl];
+    const int h = lv.H[lvl], w = lv.W[lvl];
+    const int per_img = tt.tiles_x[lvl] * tt.tiles_y[lvl];
+    const int b = t / per_img;
+    t -= b * per_img;
+    const int ty0 = (t / tt.tiles_x[lvl]) * GT_H, tx0 = (t % tt.tiles_x[lvl]) * GT_W;
+    const int group = blockIdx.y;
+    const int cpg = (lv.C + GATE_GROUPS - 1) / GATE_GROUPS;
+    const int c_begin = group * cpg;
+    const int c_end = c_begin + cpg < lv.C ? c_begin + cpg : lv.C;
+
+    const int tid = threadIdx.x;
+    const int row = tid >> 4, j = tid & 15;        // output pixel (ty0+row, tx0+4j .. +3)
+    float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* xb = x.p[lvl] + (int64_t)b * lv.C * h * w;
+    const float* W1 = w1.p[lvl];
+    const float* W2 = w2.p[lvl];
+
+    for (int c0 = c_begin; c0 < c_end; c0 += GT_CC) {
+        // ---- stage GT_CC channels x 18 rows x (64 + 2 halo) columns ----
+        for (int q = tid; q < GT_CC * (GT_H + 2) * 16; q += 256) {
+            const int cj = q & 15, rr = (q >> 4) % (GT_H + 2), cc = q / (16 * (GT_H + 2));
+            const int gy = ty0 - 1 + rr, gx = tx0 + 4 * cj, c = c0 + cc;
+            float4_u v = {0.f, 0.f, 0.f, 0.f};
+            if (c < c_end && gy >= 0 && gy < h) {
+                const float* src = xb + ((int64_t)c * h + gy) * w + gx;
+                if (gx + 3 < w) v = *reinterpret_cast<const float4_u*>(src);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (gx + e < w) v[e] = src[e];
+                }
+            }
+            *reinterpret_cast<float4*>(&tile[cc][rr][4 + 4 * cj]) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        for (int q = tid; q < GT_CC * (GT_H + 2) * 2; q += 256) {
+            const int side = q & 1, rr = (q >> 1) % (GT_H + 2), cc = q / (2 * (GT_H + 2));
+            const int gy = ty0 - 1 + rr, gx = side ? tx0 + GT_W : tx0 - 1, c = c0 + cc;
+            float v = 0.f;
+            if (c < c_end && gy >= 0 && gy < h && gx >= 0 && gx < w) v = xb[((int64_t)c * h + gy) * w + gx];
+            tile[cc][rr][side ? 4 + GT_W : 3] = v;
+        }
+        __syncthreads();
+        // ---- 18 taps x 4 px per channel ----
+#pragma unroll 2
+        for (int cc = 0; cc < GT_CC; ++cc) {
+            const int c = c0 + cc;
+            if (c >= c_end) break;
+            const float* k1 = W1 + c * 9;
+            const float* k2 = W2 + c * 9;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const float* r = &tile[cc][row + dy][4 * j + 3];
+                const float4 mid = *reinterpret_cast<const float4*>(r + 1);
+                const float v[6] = {r[0], mid.x, mid.y, mid.z, mid.w, r[5]};
+                const float u0 = k1[dy * 3 + 0], u1 = k1[dy * 3 + 1], u2 = k1[dy * 3 + 2];
+                const float s0 = k2[dy * 3 + 0], s1 = k2[dy * 3 + 1], s2 = k2[dy * 3 + 2];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    a1[e] += u0 * v[e] + u1 * v[e + 1] + u2 * v[e + 2];
+                    a2[e] += s0 * v[e] + s1 * v[e + 1] + s2 * v[e + 2];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    const int oy = ty0 + row;
+    if (oy < h) {
+        float* p1 = pre + (int64_t)group * 2 * pre_total + tt.px_off[lvl] + ((int64_t)b * h + oy) * w;
+        float* p2 = p1 + pre_total;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ox = tx0 + 4 * j + e;
+            if (ox < w) { p1[ox] = a1[e]; p2[ox] = a2[e]; }
+        }
+    }
+}
+
+// a = tanh(relu(sum_groups pre + bias))
+__global__ void fpn_gate_finish_kernel(Levels lv, TileTable tt, const float* __restrict__ pre, int64_t pre_total,
+                                       LevelPtrs b1, LevelPtrs b2, LevelMutPtrs a, LevelMutPtrs b) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= pre_total) return;
+    int lvl = 0;
+    while (lvl + 1 < lv.n && i >= tt.px_off[lvl + 1]) ++lvl;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int g = 0; g < GATE_GROUPS; ++g) {
+        s1 += pre[(int64_t)g * 2 * pre_total + i];
+        s2 += pre[(int64_t)g * 2 * pre_total + pre_total + i];
+    }
+    s1 += b1.p[lvl][0];
+    s2 += b2.p[lvl][0];
+    const int64_t o = i - tt.px_off[lvl];
+    a.p[lvl][o] = tanhf(fmaxf(s1, 0.f));
+    b.p[lvl][o] = tanhf(fmaxf(s2, 0.f));
+}
+
+// =========================================================================================================
+// scatter + gate + residual: out = x + nearest(bsf)[c] * (a + b); one thread per 4 consecutive pixels
+// =========================================================================================================
+struct QuadTable {
+    int64_t first[NL_ + 1];   // prefix sum over levels of B*C*h*ceil(w/4)
+    int wq[NL_];
+};
+
+__global__ __launch_bounds__(256) void fpn_scatter_fwd_kernel(Levels lv, QuadTable qt, LevelPtrs x, const float* __restrict__ bsf,
+                                                              LevelPtrs a, LevelPtrs b, LevelMutPtrs out) {
+    int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= qt.first[lv.n]) return;
+    int lvl = 0;
+    while (lvl + 1 < lv.n && q >= qt.first[lvl + 1]) ++lvl;
+    q -= qt.first[lvl];
+    const int h = lv.H[lvl], w = lv.W[lvl], wq = qt.wq[lvl];
+    const int hr = lv.H[lv.r], wr = lv.W[lv.r];
+    const int x0 = (int)(q % wq) * 4;
+    const int y = (int)((q / wq) % h);
+    const int64_t bc = q / ((int64_t)wq * h);
+    const int bi = (int)(bc / lv.C);
+    const float sy_scale = nearest_scale(hr, h), sx_scale = nearest_scale(wr, w);
+    const int sy = nearest_src(y, hr, sy_scale);
+    const float* brow = bsf + (bc * hr + sy) * (int64_t)wr;
+    const int64_t off = (bc * h + y) * (int64_t)w + x0;
+    const int64_t moff = ((int64_t)bi * h + y) * w + x0;
+    const float* xp = x.p[lvl] + off;
+    float* op = out.p[lvl] + off;
+    if (x0 + 3 < w) {
+        float4_u xv = *reinterpret_cast<const float4_u*>(xp);
+        float4_u av = *reinterpret_cast<const float4_u*>(a.p[lvl] + moff);
+        float4_u bv = *reinterpret_cast<const float4_u*>(b.p[lvl] + moff);
+        float4_u o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float u = brow[nearest_src(x0 + e, wr, sx_scale)];
+            o[e] = xv[e] + u * (av[e] + bv[e]);
+        }
+        *reinterpret_cast<float4_u*>(op) = o;
+    } else {
+        for (int e = 0; e < 4 && x0 + e < w; ++e) {
+            const float u = brow[nearest_src(x0 + e, wr, sx_scale)];
+            op[e] = xp[e] + u * (a.p[lvl][moff + e] + b.p[lvl][moff + e]);
+        }
+    }
+}
+
+// =========================================================================================================
+// backward A: dm_i = sum_c g_i[c] * U(bsf)[c]  -> dpre_a = dm (1 - a^2) [a > 0], dpre_b likewise.
+//   block = 64 pixel quads x 4 channel quarters; the quarters are reduced through LDS.
+// =========================================================================================================
+struct PixQuadTable {
+    int64_t first[NL_ + 1];   // prefix sum over levels of B*h*ceil(w/4)
+    int wq[NL_];
+};
+
+__global__ __launch_bounds__(256) void fpn_scatter_bwd_maps_kernel(Levels lv, PixQuadTable pt, LevelPtrs gout,
+                                                                   const float* __restrict__ bsf, LevelPtrs a, LevelPtrs b,
+                                                                   LevelMutPtrs dpa, LevelMutPtrs dpb) {
+    __shared__ float red[3][64][4];
+    const int lq = threadIdx.x & 63, quarter = threadIdx.x >> 6;
+    int64_t q = (int64_t)blockIdx.x * 64 + lq;
+    const bool active = q < pt.first[lv.n];
+    float dm[4] = {0.f, 0.f, 0.f, 0.f};
+    int lvl = 0, h = 1, w = 1, x0 = 0, y = 0, bi = 0;
+    if (active) {
+        while (lvl + 1 < lv.n && q >= pt.first[lvl + 1]) ++lvl;
+        q -= pt.first[lvl];
+        h = lv.H[lvl]; w = lv.W[lvl];
+        const int wq = pt.wq[lvl];
+        x0 = (int)(q % wq) * 4;
+        y = (int)((q / wq) % h);
+        bi = (int)(q / ((int64_t)wq * h));
+        const int hr = lv.H[lv.r], wr = lv.W[lv.r];
+        const float sy_scale = nearest_scale(hr, h), sx_scale = nearest_scale(wr, w);
+        const int sy = nearest_src(y, hr, sy_scale);
+        int sx[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sx[e] = nearest_src(x0 + e < w ? x0 + e : w - 1, wr, sx_scale);
+        const int cq = (lv.C + 3) / 4;
+        const int c_begin = quarter * cq, c_end = c_begin + cq < lv.C ? c_begin + cq : lv.C;
+        const bool full = x0 + 3 < w;
+        const float* gp = gout.p[lvl] + (((int64_t)bi * lv.C + c_begin) * h + y) * w + x0;
+        const float* bp = bsf + (((int64_t)bi * lv.C + c_begin) * hr + sy) * wr;
+        const int64_t gstep = (int64_t)h * w, bstep = (int64_t)hr * wr;
+#pragma unroll 4
+        for (int c = c_begin; c < c_end; ++c) {
+            float4_u gv = {0.f, 0.f, 0.f, 0.f};
+            if (full) gv = *reinterpret_cast<const float4_u*>(gp);
+            else for (int e = 0; e < 4 && x0 + e < w; ++e) gv[e] = gp[e];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dm[e] += gv[e] * bp[sx[e]];
+            gp += gstep; bp += bstep;
+        }
+    }
+    if (quarter > 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[quarter - 1][lq][e] = dm[e];
+    }
+    __syncthreads();
+    if (quarter == 0 && active) {
+        const int64_t moff = ((int64_t)bi * h + y) * w + x0;
+        for (int e = 0; e < 4 && x0 + e < w; ++e) {
+            const float d = ((dm[e] + red[0][lq][e]) + red[1][lq][e]) + red[2][lq][e];
+            const float av = a.p[lvl][moff + e], bv = b.p[lvl][moff + e];
+            dpa.p[lvl][moff + e] = av > 0.f ? d * (1.f - av * av) : 0.f;
+            dpb.p[lvl][moff + e] = bv > 0.f ? d * (1.f - bv * bv) : 0.f;
+        }
+    }
+}
+
+// backward B: dbsf[b,c,sy,sx] = sum_i sum_{dst -> (sy,sx)} g_i[c,dst] (a_i + b_i)[dst]
+__global__ __launch_bounds__(256) void fpn_scatter_bwd_dbsf_kernel(Levels lv, LevelPtrs gout, LevelPtrs a, LevelPtrs b,
+                                                                   float* __restrict__ dbsf) {
+    const int hr = lv.H[lv.r], wr = lv.W[lv.r];
+    const int64_t total = (int64_t)lv.B * lv.C * hr * wr;
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int sx = (int)(idx % wr);
+    const int sy = (int)((idx / wr) % hr);
+    const int64_t bc = idx / ((int64_t)wr * hr);
+    const int bi = (int)(bc / lv.C);
+    float acc = 0.f;
+    for (int i = 0; i < lv.n; ++i) {
+        const int h = lv.H[i], w = lv.W[i];
+        const float ys = nearest_scale(hr, h), xs = nearest_scale(wr, w);
+        const int y0 = nearest_dst_begin(sy, hr, h, ys), y1 = nearest_dst_begin(sy + 1, hr, h, ys);
+        const int x0 = nearest_dst_begin(sx, wr, w, xs), x1 = nearest_dst_begin(sx + 1, wr, w, xs);
+        const float* gp = gout.p[i] + bc * (int64_t)h * w;
+        const float* ap = a.p[i] + (int64_t)bi * h * w;
+        const float* bp = b.p[i] + (int64_t)bi * h * w;
+        if (x1 - x0 == 4) {
+            for (int yy = y0; yy < y1; ++yy) {
+                const int64_t o = (int64_t)yy * w + x0;
+                float4_u gv = *reinterpret_cast<const float4_u*>(gp + o);
+                float4_u av = *reinterpret_cast<const float4_u*>(ap + o);
+                float4_u bv = *reinterpret_cast<const float4_u*>(bp + o);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc += gv[e] * (av[e] + bv[e]);
+            }
+        } else {
+            for (int yy = y0; yy < y1; ++yy)
+                for (int xx = x0; xx < x1; ++xx) {
+                    const int64_t o = (int64_t)yy * w + xx;
+                    acc += gp[o] * (ap[o] + bp[o]);
+                }
+        }
+    }
+    dbsf[idx] = acc;
+}
+
+// =========================================================================================================
+// backward C: dx = g + conv3x3^T(dpre_a; w1) + conv3x3^T(dpre_b; w2) + gather^T(dm / n)
+// =========================================================================================================
+__global__ __launch_bounds__(256) void fpn_input_bwd_kernel(Levels lv, QuadTable qt, LevelPtrs gout, LevelPtrs dpa,
+                                                            LevelPtrs dpb, LevelPtrs w1, LevelPtrs w2,
+                                                            const float* __restrict__ dm, const int32_t* __restrict__ argmax,
+                                                            LevelMutPtrs dx) {
+    int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= qt.first[lv.n]) return;
+    int lvl = 0;
+    while (lvl + 1 < lv.n && q >= qt.first[lvl + 1]) ++lvl;
+    q -= qt.first[lvl];
+    const int h = lv.H[lvl], w = lv.W[lvl], wq = qt.wq[lvl];
+    const int hr = lv.H[lv.r], wr = lv.W[lv.r];
+    const int x0 = (int)(q % wq) * 4;
+    const int y = (int)((q / wq) % h);
+    const int64_t bc = q / ((int64_t)wq * h);
+    const int c = (int)(bc % lv.C), bi = (int)(bc / lv.C);
+    const int64_t off = (bc * h + y) * (int64_t)w + x0;
+
+    float r[4];
+    {
+        const float* gp = gout.p[lvl] + off;
+        if (x0 + 3 < w) {
+            float4_u gv = *reinterpret_cast<const float4_u*>(gp);
+            r[0] = gv[0]; r[1] = gv[1]; r[2] = gv[2]; r[3] = gv[3];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = x0 + e < w ? gp[e] : 0.f;
+        }
+    }
+    // transposed 3x3 conv of the two 1-channel maps: dx[y,x] += sum_{ky,kx} W[c,ky,kx] * d[y-(ky-1), x-(kx-1)]
+    {
+        const float* k1 = w1.p[lvl] + c * 9;
+        const float* k2 = w2.p[lvl] + c * 9;
+        const float* da = dpa.p[lvl] + (int64_t)bi * h * w;
+        const float* db = dpb.p[lvl] + (int64_t)bi * h * w;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int yy = y - (ky - 1);
+            if (yy < 0 || yy >= h) continue;
+            float va[6], vb[6];
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {
+                const int xx = x0 - 1 + t;
+                const bool ok = xx >= 0 && xx < w;
+                va[t] = ok ? da[(int64_t)yy * w + xx] : 0.f;
+                vb[t] = ok ? db[(int64_t)yy * w + xx] : 0.f;
+            }
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const float u = k1[ky * 3 + kx], s = k2[ky * 3 + kx];
+                // source column = x - (kx-1)  ->  window index (e + 1) - (kx - 1) = e + 2 - kx
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[e] += u * va[e + 2 - kx] + s * vb[e + 2 - kx];
+            }
+        }
+    }
+    // gather^T
+    const float inv_n = (float)lv.n;
+    const int64_t plane_r = (int64_t)hr * wr;
+    const float* dmp = dm + bc * plane_r;
+    if (lvl < lv.r) {
+        const int32_t* am = argmax + (int64_t)lvl * lv.B * lv.C * plane_r + bc * plane_r;
+        int oy0 = (int)(((int64_t)y * hr) / h) - 1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int xx = x0 + e;
+            if (xx >= w) break;
+            const int ox0 = (int)(((int64_t)xx * wr) / w) - 1;
+            const int flat = y * w + xx;
+            for (int oy = oy0; oy <= oy0 + 2; ++oy) {
+                if (oy < 0 || oy >= hr) continue;
+                if (y < pool_start(oy, h, hr) || y >= pool_end(oy, h, hr)) continue;
+                for (int ox = ox0; ox <= ox0 + 2; ++ox) {
+                    if (ox < 0 || ox >= wr) continue;
+                    if (xx < pool_start(ox, w, wr) || xx >= pool_end(ox, w, wr)) continue;
+                    if (am[(int64_t)oy * wr + ox] == flat) r[e] += dmp[(int64_t)oy * wr + ox] / inv_n;
+                }
+            }
+        }
+    } else {
+        const float ys = nearest_scale(h, hr), xs = nearest_scale(w, wr);
+        const int py0 = nearest_dst_begin(y, h, hr, ys), py1 = nearest_dst_begin(y + 1, h, hr, ys);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int xx = x0 + e;
+            if (xx >= w) break;
+            const int px0 = nearest_dst_begin(xx, w, wr, xs), px1 = nearest_dst_begin(xx + 1, w, wr, xs);
+            float s = 0.f;
+            for (int py = py0; py < py1; ++py)
+                for (int px = px0; px < px1; ++px) s += dmp[(int64_t)py * wr + px] / inv_n;
+            r[e] += s;
+        }
+    }
+    float* op = dx.p[lvl] + off;
+    if (x0 + 3 < w) {
+        float4_u o = {r[0], r[1], r[2], r[3]};
+        *reinterpret_cast<float4_u*>(op) = o;
+    } else {
+        for (int e = 0; e < 4 && x0 + e < w; ++e) op[e] = r[e];
+    }
+}
+
+// =========================================================================================================
+// gate-conv weight gradients: dw[c,ky,kx] = sum_{b,y,x} x[c, y+ky-1, x+kx-1] * dpre[y,x]
+//   block = (row chunk, channel, level*B + b); each thread walks pixels of the chunk, 18 accumulators.
+// =========================================================================================================
+constexpr int WG_ROWS = 8;
+__global__ __launch_bounds__(256) void fpn_gate_wgrad_kernel(Levels lv, int lvl, const float* __restrict__ x,
+                                                             const float* __restrict__ dpa, const float* __restrict__ dpb,
+                                                             float* __restrict__ dw1, float* __restrict__ db1,
+                                                             float* __restrict__ dw2, float* __restrict__ db2) {
+    const int h = lv.H[lvl], w = lv.W[lvl];
+    const int c = blockIdx.y, bi = blockIdx.z;
+    const int y_begin = blockIdx.x * WG_ROWS;
+    const int y_end = y_begin + WG_ROWS < h ? y_begin + WG_ROWS : h;
+    // input rows that touch output rows [y_begin, y_end): [y_begin-1, y_end+1) clipped; to count every product
+    // exactly once the block owns the x rows [y_begin, y_end) and pairs them with dpre rows yy-(ky-1).
+    const float* xp = x + ((int64_t)bi * lv.C + c) * h * w;
+    const float* da = dpa + (int64_t)bi * h * w;
+    const float* db = dpb + (int64_t)bi * h * w;
+    float s1[9], s2[9], sa = 0.f, sb = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) { s1[t] = 0.f; s2[t] = 0.f; }
+    const int npx = (y_end - y_begin) * w;
+    for (int i = threadIdx.x; i < npx; i += 256) {
+        const int yy = y_begin + i / w, xx = i % w;
+        const float xv = xp[(int64_t)yy * w + xx];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int oy = yy - (ky - 1);
+            if (oy < 0 || oy >= h) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ox = xx - (kx - 1);
+                if (ox < 0 || ox >= w) continue;
+                s1[ky * 3 + kx] += xv * da[(int64_t)oy * w + ox];
+                s2[ky * 3 + kx] += xv * db[(int64_t)oy * w + ox];
+            }
+        }
+        if (c == 0) { sa += da[(int64_t)yy * w + xx]; sb += db[(int64_t)yy * w + xx]; }
+    }
+    __shared__ float red[4][20];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        float v1 = wave_sum(s1[t]), v2 = wave_sum(s2[t]);
+        if (lane == 0) { red[wv][t] = v1; red[wv][9 + t] = v2; }
+    }
+    {
+        float v1 = wave_sum(sa), v2 = wave_sum(sb);
+        if (lane == 0) { red[wv][18] = v1; red[wv][19] = v2; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 20) {
+        const int t = threadIdx.x;
+        const float v = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+        if (t < 9) unsafeAtomicAdd(dw1 + c * 9 + t, v);
+        else if (t < 18) unsafeAtomicAdd(dw2 + c * 9 + (t - 9), v);
+        else if (c == 0) unsafeAtomicAdd(t == 18 ? db1 : db2, v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+static TileTable make_tile_table(const Levels& lv) {
+    TileTable tt;
+    int acc = 0;
+    int64_t px = 0;
+    for (int i = 0; i < NL_; ++i) {
+        if (i < lv.n) {
+            tt.tiles_x[i] = cdiv(lv.W[i], GT_W);
+            tt.tiles_y[i] = cdiv(lv.H[i], GT_H);
+            tt.first_tile[i] = acc;
+            tt.px_off[i] = px;
+            acc += tt.tiles_x[i] * tt.tiles_y[i] * lv.B;
+            px += (int64_t)lv.B * lv.H[i] * lv.W[i];
+        } else {
+            tt.tiles_x[i] = tt.tiles_y[i] = 0;
+            tt.first_tile[i] = acc;
+            tt.px_off[i] = px;
+        }
+    }
+    tt.first_tile[NL_] = acc;
+    tt.px_off[NL_] = px;
+    for (int i = lv.n; i <= NL_; ++i) { tt.first_tile[i] = acc; tt.px_off[i] = px; }
+    return tt;
+}
+static QuadTable make_quad_table(const Levels& lv) {
+    QuadTable qt;
+    int64_t acc = 0;
+    for (int i = 0; i <= NL_; ++i) {
+        qt.first[i] = acc;
+        if (i < NL_) {
+            qt.wq[i] = i < lv.n ? cdiv(lv.W[i], 4) : 0;
+            if (i < lv.n) acc += (int64_t)lv.B * lv.C * lv.H[i] * qt.wq[i];
+        }
+    }
+    return qt;
+}
+static PixQuadTable make_pixquad_table(const Levels& lv) {
+    PixQuadTable pt;
+    int64_t acc = 0;
+    for (int i = 0; i <= NL_; ++i) {
+        pt.first[i] = acc;
+        if (i < NL_) {
+            pt.wq[i] = i < lv.n ? cdiv(lv.W[i], 4) : 0;
+            if (i < lv.n) acc += (int64_t)lv.B * lv.H[i] * pt.wq[i];
+        }
+    }
+    return pt;
+}
+template <class T>
+static bool fill_ptrs(T& dst, const float* const* src, int n) {
+    for (int i = 0; i < NL_; ++i) dst.p[i] = nullptr;
+    if (!src) return false;
+    for (int i = 0; i < n; ++i) {
+        if (!src[i]) return false;
+        dst.p[i] = const_cast<float*>(src[i]);
+    }
+    return true;
+}
+
+}  // namespace arfe
+
+using namespace arfe;
+
+extern "C" int64_t arfe_fpn_gatemap_workspace_bytes(const arfe_pyramid_t* pyr) {
+    if (check_pyramid(pyr)) return -1;
+    int64_t px = 0;
+    for (int i = 0; i < pyr->num_levels; ++i) px += (int64_t)pyr->batch * pyr->height[i] * pyr->width[i];
+    return (int64_t)GATE_GROUPS * 2 * px * (int64_t)sizeof(float);
+}
+
+extern "C" int32_t arfe_fpn_gather_fwd(const arfe_pyramid_t* pyr, const float* const* x, float* m, int32_t* argmax,
+                                       void* stream) {
+    int32_t rc = check_pyramid(pyr);
+    if (rc) return rc;
+    Levels lv = to_levels(pyr);
+    LevelPtrs xp;
+    ARFE_CHECK_ARG(fill_ptrs(xp, x, lv.n) && m, ARFE_ERR_ARG, "fpn_gather_fwd: null pointer");
+    const int64_t total = (int64_t)lv.B * lv.C * lv.H[lv.r] * lv.W[lv.r];
+    hipLaunchKernelGGL(fpn_gather_fwd_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, as_stream(stream), lv, xp,
+                       m, argmax);
+    ARFE_CHECK_LAUNCH();
+    return ARFE_OK;
+}
+
+extern "C" int32_t arfe_fpn_gatemap_fwd(const arfe_pyramid_t* pyr, const float* const* x, const float* const* w1,
+                                        const float* const* b1, const float* const* w2, const float* const* b2,
+                                        float* const* a, float* const* b, void* workspace, void* stream) {
+    int32_t rc = check_pyramid(pyr);
+    if (rc) return rc;
+    Levels lv = to_levels(pyr);
+    LevelPtrs xp, w1p, w2p, b1p, b2p;
+    LevelMutPtrs ap, bp;
+    ARFE_CHECK_ARG(fill_ptrs(xp, x, lv.n) && fill_ptrs(w1p, w1, lv.n) && fill_ptrs(w2p, w2, lv.n) &&
+                       fill_ptrs(b1p, b1, lv.n) && fill_ptrs(b2p, b2, lv.n) && fill_ptrs(ap, a, lv.n) &&
+                       fill_ptrs(bp, b, lv.n) && workspace,
+                   ARFE_ERR_ARG, "fpn_gatemap_fwd: null pointer");
+    TileTable tt = make_tile_table(lv);
+    const int64_t pre_total = tt.px_off[lv.n];
+    float* pre = (float*)workspace;
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(fpn_gate_partial_kernel, dim3(tt.first_tile[lv.n], GATE_GROUPS), dim3(256), 0, st, lv, tt, xp, w1p,
+                       w2p, pre, pre_total);
+    ARFE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(fpn_gate_finish_kernel, dim3((unsigned)cdiv64(pre_total, 256)), dim3(256), 0, st, lv, tt, pre,
+                       pre_total, b1p, b2p, ap, bp);
+    ARFE_CHECK_LAUNCH();
+    return ARFE_OK;
+}
+
+extern "C" int32_t arfe_fpn_scatter_fwd(const arfe_pyramid_t* pyr, const float* const* x, const float* bsf,
+                                        const float* const* a, const float* const* b, float* const* out, void* stream) {
+    int32_t rc = check_pyramid(pyr);
+    if (rc) return rc;
+    Levels lv = to_levels(pyr);
+    LevelPtrs xp, ap, bp;
+    LevelMutPtrs op;
+    ARFE_CHECK_ARG(fill_ptrs(xp, x, lv.n) && fill_ptrs(ap, a, lv.n) && fill_ptrs(bp, b, lv.n) &&
+                       fill_ptrs(op, out, lv.n) && bsf,
+                   ARFE_ERR_ARG, "fpn_scatter_fwd: null pointer");
+    QuadTable qt = make_quad_table(lv);
+    hipLaunchKernelGGL(fpn_scatter_fwd_kernel, dim3((unsigned)cdiv64(qt.first[lv.n], 256)), dim3(256), 0,
+                       as_stream(stream), lv, qt, xp, bsf, ap, bp, op);
+    ARFE_CHECK_LAUNCH();
+    return ARFE_OK;
+}
+
+extern "C" int32_t arfe_fpn_scatter_bwd(const arfe_pyramid_t* pyr, const float* const* gout, const float* bsf,
+                                        const float* const* a, const float* const* b, float* const* dpre_a,
+                                        float* const* dpre_b, float* dbsf, void* stream) {
+    int32_t rc = check_pyramid(pyr);
+    if (rc) return rc;
+    Levels lv = to_levels(pyr);
+    LevelPtrs gp, ap, bp;
+    LevelMutPtrs dap, dbp;
+    ARFE_CHECK_ARG(fill_ptrs(gp, gout, lv.n) && fill_ptrs(ap, a, lv.n) && fill_ptrs(bp, b, lv.n) &&
+                       fill_ptrs(dap, dpre_a, lv.n) && fill_ptrs(dbp, dpre_b, lv.n) && bsf && dbsf,
+                   ARFE_ERR_ARG, "fpn_scatter_bwd: null pointer");
+    hipStream_t st = as_stream(stream);
+    PixQuadTable pt = make_pixquad_table(lv);
+    hipLaunchKernelGGL(fpn_scatter_bwd_maps_kernel, dim3((unsigned)cdiv64(pt.first[lv.n], 64)), dim3(256), 0, st, lv, pt,
+                       gp, bsf, ap, bp, dap, dbp);
+    ARFE_CHECK_LAUNCH();
+    const int64_t total = (int64_t)lv.B * lv.C * lv.H[lv.r] * lv.W[lv.r];
+    hipLaunchKernelGGL(fpn_scatter_bwd_dbsf_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, lv, gp, ap, bp,
+                       dbsf);
+    ARFE_CHECK_LAUNCH();
+    return ARFE_OK;
+}
+
+extern "C" int32_t arfe_fpn_input_bwd(const arfe_pyramid_t* pyr, const float* const* gout, const float* const* dpre_a,
+                                      const float* const* dpre_b, const float* const* w1, const float* const* w2,
+                                      const float* dm, const int32_t* argmax, float* const* dx, void* stream) {
+    int32_t rc = check_pyramid(pyr);
+    if (rc) return rc;
+    Levels lv = to_levels(pyr);
+    LevelPtrs gp, dap, dbp, w1p, w2p;
+    LevelMutPtrs dxp;
+    ARFE_CHECK_ARG(fill_ptrs(gp, gout, lv.n) && fill_ptrs(dap, dpre_a, lv.n) && fill_ptrs(dbp, dpre_b, lv.n) &&
+                       fill_ptrs(w1p, w1, lv.n) && fill_ptrs(w2p, w2, lv.n) && fill_ptrs(dxp, dx, lv.n) && dm &&
+                       (argmax || lv.r == 0),
+                   ARFE_ERR_ARG, "fpn_input_bwd: null pointer");
+    QuadTable qt = make_quad_table(lv);
+    hipLaunchKernelGGL(fpn_input_bwd_kernel, dim3((unsigned)cdiv64(qt.first[lv.n], 256)), dim3(256), 0, as_stream(stream),
+                       lv, qt, gp, dap, dbp, w1p, w2p, dm, argmax, dxp);
+    ARFE_CHECK_LAUNCH();
+    return ARFE_OK;
+}
+
+extern "C" int32_t arfe_fpn_gate_wgrad(const arfe_pyramid_t* pyr, const float* const* x, const float* const* dpre_a,
+                                       const float* const* dpre_b, float* const* dw1, float* const* db1,
+                                       float* const* dw2, float* const* db2, void* stream) {
+    int32_t rc = check_pyramid(pyr);
+    if (rc) return rc;
+    Levels lv = to_levels(pyr);
+    hipStream_t st = as_stream(stream);
+    ARFE_CHECK_ARG(x && dpre_a && dpre_b && dw1 && db1 && dw2 && db2, ARFE_ERR_ARG, "fpn_gate_wgrad: null pointer");
+    for (int i = 0; i < lv.n; ++i) {
+        ARFE_CHECK_ARG(x[i] && dpre_a[i] && dpre_b[i] && dw1[i] && db1[i] && dw2[i] && db2[i], ARFE_ERR_ARG,
+                       "fpn_gate_wgrad: null pointer at level %d", i);
+        if (hipMemsetAsync(dw1[i], 0, sizeof(float) * 9 * lv.C, st) != hipSuccess ||
+            hipMemsetAsync(dw2[i], 0, sizeof(float) * 9 * lv.C, st) != hipSuccess ||
+            hipMemsetAsync(db1[i], 0, sizeof(float), st) != hipSuccess ||
+            hipMemsetAsync(db2[i], 0, sizeof(float), st) != hipSuccess) {
+            set_error("fpn_gate_wgrad: memset failed");
+            return ARFE_ERR_LAUNCH;
+        }
+        dim3 grid(cdiv(lv.H[i], WG_ROWS), lv.C, lv.B);
+        hipLaunchKernelGGL(fpn_gate_wgrad_kernel, grid, dim3(256), 0, st, lv, i, x[i], dpre_a[i], dpre_b[i], dw1[i], db1[i],
+                           dw2[i], db2[i]);
+        ARFE_CHECK_LAUNCH();
+    }
+    return ARFE_OK;
+}

@@ -1,0 +1,219 @@
+// Exact-fp32 tiled GEMM on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32: bitwise an fp32 fma chain,
+// 64 FLOP/clk/SIMD = 157 TFLOP/s chip peak).  One kernel template serves every dense contraction of the
+// AR path -- NonLocal 1x1 convs / theta^T phi / P g^T and their gradients, the AR-RFF 3x3 convs (implicit
+// GEMM, shifted-tap loaders) and the FC layers -- through small loader/epilogue functors.
+//
+//   C[m][n] (+)= sum_k A(m,k) * B(k,n)          tile 128x128x16, 256 threads = 4 waves (2x2), wave = 64x64
+//
+//   * LDS images are k-major (As[k][m], Bs[k][n], row pad 4) so the MFMA operand fetch
+//     (lane l -> element [k = l>>5][m = l&31]) is one conflict-free ds_read_b32 per operand.
+//   * global -> register -> LDS double buffering: the loads of K-step t+1 are in flight while step t runs
+//     on the matrix pipe; one barrier per K-step.
+//   * blockIdx.x = output tile (XCD-aware remap: tiles that share an A panel land on one XCD's L2),
+//     blockIdx.y = split-K slice (atomic epilogue), blockIdx.z = batch.
+//   * K may be "batched": K = kb_count * k_inner, the loaders see (kb, k) so a reduction over images
+//     (weight gradients) needs no extra pass.
+#pragma once
+#include "common.hpp"
+
+namespace arfe {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_BK = 16;
+constexpr int GEMM_LDS_LD = 132;  // 128 + 4 pad (floats)
+
+struct GemmDims {
+    int M, N, K;        // K = inner extent per k-batch
+    int kb_count;       // number of k-batches folded into the reduction (>= 1)
+    int tiles_m, tiles_n;
+    int splitk;         // gridDim.y
+    int ksteps_total;   // kb_count * ceil(K / BK)
+};
+
+// ---- operand loaders: return A(m,k) / B(k,n) for batch z and k-batch kb, 0 outside the matrix ------------
+// `kfast` tells the kernel which index is contiguous in memory so that consecutive lanes read consecutive
+// addresses.
+
+struct LoadRowMajorK {   // element(i, k) = p[z*sz + kb*skb + i*ld + k]     (k contiguous)
+    const float* p; int64_t sz, skb; int64_t ld; int rows, K;
+    static constexpr bool kfast = true;
+    __device__ __forceinline__ float operator()(int z, int kb, int i, int k) const {
+        return (i < rows && k < K) ? p[z * sz + kb * skb + (int64_t)i * ld + k] : 0.f;
+    }
+};
+struct LoadRowMajorI {   // element(i, k) = p[z*sz + kb*skb + k*ld + i]     (i contiguous)
+    const float* p; int64_t sz, skb; int64_t ld; int rows, K;
+    static constexpr bool kfast = false;
+    __device__ __forceinline__ float operator()(int z, int kb, int i, int k) const {
+        return (i < rows && k < K) ? p[z * sz + kb * skb + (int64_t)k * ld + i] : 0.f;
+    }
+};
+
+// ---- epilogues ------------------------------------------------------------------------------------------
+struct EpiPlain {   // C[z*sz + m*ld + n] ; optional bias per row (m) or per column (n), optional ReLU,
+                    // optional residual add (same layout as C), beta (0: overwrite, 1: accumulate)
+    float* c; int64_t sz, ld;
+    const float* bias_m; const float* bias_n; const float* residual;
+    int relu; int accumulate; int atomic;
+    __device__ __forceinline__ void operator()(int z, int m, int n, float v, bool first_split) const {
+        int64_t o = z * sz + (int64_t)m * ld + n;
+        if (first_split) {
+            if (bias_m) v += bias_m[m];
+            if (bias_n) v += bias_n[n];
+            if (residual) v += residual[o];
+        }
+        if (atomic) { unsafeAtomicAdd(c + o, v); return; }
+        if (accumulate) v += c[o];
+        if (relu) v = fmaxf(v, 0.f);
+        c[o] = v;
+    }
+};
+
+template <class LA, class LB, class EPI>
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmDims d, LA la, LB lb, EPI epi) {
+    __shared__ float As[2][GEMM_BK][GEMM_LDS_LD];
+    __shared__ float Bs[2][GEMM_BK][GEMM_LDS_LD];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int z = blockIdx.z;
+
+    // XCD-aware tile remap (bijective for any tile count): consecutive ids of one XCD walk along n
+    // inside one m-panel so the A panel stays in that XCD's L2.
+    int ntiles = d.tiles_m * d.tiles_n;
+    int bid = blockIdx.x;
+    {
+        int q = ntiles >> 3, r = ntiles & 7, x = bid & 7, j = bid >> 3;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+    }
+    const int tm = bid / d.tiles_n, tn = bid % d.tiles_n;
+    const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
+
+    // split-K range in units of K-steps over the (kb, k) space
+    const int ksteps_per_kb = (d.K + GEMM_BK - 1) / GEMM_BK;
+    const int per = (d.ksteps_total + d.splitk - 1) / d.splitk;
+    const int s_begin = blockIdx.y * per;
+    int s_end = s_begin + per;
+    if (s_end > d.ksteps_total) s_end = d.ksteps_total;
+    const bool first_split = (blockIdx.y == 0);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // per-thread staging coordinates: 8 elements of A and 8 of B per K-step
+    float ra[8], rb[8];
+    auto fetch = [&](int step) {
+        const int kb = step / ksteps_per_kb;
+        const int k0 = (step - kb * ksteps_per_kb) * GEMM_BK;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int mi, ki;
+            if (LA::kfast) { ki = tid & 15; mi = (tid >> 4) + 16 * i; }
+            else           { mi = tid & 127; ki = (tid >> 7) + 2 * i; }
+            ra[i] = la(z, kb, m0 + mi, k0 + ki);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int ni, ki;
+            if (LB::kfast) { ki = tid & 15; ni = (tid >> 4) + 16 * i; }
+            else           { ni = tid & 127; ki = (tid >> 7) + 2 * i; }
+            rb[i] = lb(z, kb, n0 + ni, k0 + ki);
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int mi, ki;
+            if (LA::kfast) { ki = tid & 15; mi = (tid >> 4) + 16 * i; }
+            else           { mi = tid & 127; ki = (tid >> 7) + 2 * i; }
+            As[buf][ki][mi] = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int ni, ki;
+            if (LB::kfast) { ki = tid & 15; ni = (tid >> 4) + 16 * i; }
+            else           { ni = tid & 127; ki = (tid >> 7) + 2 * i; }
+            Bs[buf][ki][ni] = rb[i];
+        }
+    };
+
+    if (s_begin < s_end) {
+        fetch(s_begin);
+        stash(0);
+        __syncthreads();
+        int buf = 0;
+        for (int s = s_begin; s < s_end; ++s) {
+            const bool more = (s + 1 < s_end);
+            if (more) fetch(s + 1);
+            const int kh = lane >> 5, l31 = lane & 31;
+#pragma unroll
+            for (int kk = 0; kk < GEMM_BK; kk += 2) {
+                float a0 = As[buf][kk + kh][wm * 64 + l31];
+                float a1 = As[buf][kk + kh][wm * 64 + 32 + l31];
+                float b0 = Bs[buf][kk + kh][wn * 64 + l31];
+                float b1 = Bs[buf][kk + kh][wn * 64 + 32 + l31];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
+            if (more) stash(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+    } else if (!first_split) {
+        return;
+    }
+
+    // epilogue: D[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31]
+    const int h = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + l31;
+            if (n >= d.N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m < d.M) epi(z, m, n, acc[i][j][r], first_split);
+            }
+        }
+}
+
+template <class LA, class LB, class EPI>
+static inline int32_t launch_gemm(int M, int N, int K, int kb_count, int batch, int splitk, LA la, LB lb, EPI epi,
+                                  hipStream_t stream) {
+    if (M <= 0 || N <= 0 || batch <= 0) return ARFE_OK;
+    GemmDims d;
+    d.M = M; d.N = N; d.K = K; d.kb_count = kb_count < 1 ? 1 : kb_count;
+    d.tiles_m = cdiv(M, GEMM_BM); d.tiles_n = cdiv(N, GEMM_BN);
+    d.ksteps_total = d.kb_count * cdiv(K, GEMM_BK);
+    if (splitk < 1) splitk = 1;
+    if (splitk > d.ksteps_total && d.ksteps_total > 0) splitk = d.ksteps_total;
+    d.splitk = splitk;
+    dim3 grid(d.tiles_m * d.tiles_n, splitk, batch);
+    hipLaunchKernelGGL((gemm_f32_kernel<LA, LB, EPI>), grid, dim3(256), 0, stream, d, la, lb, epi);
+    ARFE_CHECK_LAUNCH();
+    return ARFE_OK;
+}
+
+// how many K-slices to cut so that about one wave of workgroups per CU pair is in flight (256 CUs, 2 WG/CU)
+static inline int pick_splitk(int M, int N, int batch, int ksteps) {
+    int tiles = cdiv(M, GEMM_BM) * cdiv(N, GEMM_BN) * batch;
+    if (tiles >= 384) return 1;
+    int s = 512 / (tiles > 0 ? tiles : 1);
+    if (s < 1) s = 1;
+    int max_s = ksteps / 8;          // keep at least 8 K-steps per slice
+    if (max_s < 1) max_s = 1;
+    return s < max_s ? s : max_s;
+}
+
+}  // namespace arfe

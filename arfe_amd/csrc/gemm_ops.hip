@@ -1,0 +1,587 @@
+// Dense contractions of the AR path on the exact-fp32 MFMA GEMM (gemm_f32.hpp):
+//   NonLocal2D refine fwd/bwd, AR-RFF 3x3 convs (implicit GEMM) fwd/bwd, nn.Linear fwd/bwd.
+#include "gemm_f32.hpp"
+
+namespace arfe {
+
+// ---------------------------------------------------------------------------------------------------------
+// loaders with an optional ReLU mask (value is zeroed where mask <= 0; mask shares the value's indexing)
+// ---------------------------------------------------------------------------------------------------------
+struct LoadMaskedK {   // element(i,k) = p[i*ld + k] * [mask[i*ld+k] > 0]
+    const float* p; const float* mask; int64_t ld; int rows, K;
+    static constexpr bool kfast = true;
+    __device__ __forceinline__ float operator()(int, int, int i, int k) const {
+        if (i >= rows || k >= K) return 0.f;
+        int64_t o = (int64_t)i * ld + k;
+        float v = p[o];
+        if (mask && !(mask[o] > 0.f)) v = 0.f;
+        return v;
+    }
+};
+struct LoadMaskedI {   // element(i,k) = p[k*ld + i] * [mask > 0]
+    const float* p; const float* mask; int64_t ld; int rows, K;
+    static constexpr bool kfast = false;
+    __device__ __forceinline__ float operator()(int, int, int i, int k) const {
+        if (i >= rows || k >= K) return 0.f;
+        int64_t o = (int64_t)k * ld + i;
+        float v = p[o];
+        if (mask && !(mask[o] > 0.f)) v = 0.f;
+        return v;
+    }
+};
+
+// ---- 3x3 conv on [R,C,7,7] RoI tiles as 9 shifted GEMMs (k-batch = tap) ------------------------------------
+struct ConvGatherB {   // B(n=(r,p), k=ci) for tap kb: x[r*roi_stride + ci*49 + shift(p, tap)], 0 outside the 7x7 tile
+    const float* x; const float* mask; int64_t roi_stride, mask_roi_stride; int N, Cin;
+    static constexpr bool kfast = false;
+    __device__ __forceinline__ float operator()(int, int kb, int n, int k) const {
+        if (n >= N || k >= Cin) return 0.f;
+        int r = n / 49, p = n - r * 49;
+        int py = p / 7, px = p - py * 7;
+        int yy = py + kb / 3 - 1, xx = px + kb % 3 - 1;
+        if ((unsigned)yy >= 7u || (unsigned)xx >= 7u) return 0.f;
+        int q = k * 49 + yy * 7 + xx;
+        float v = x[(int64_t)r * roi_stride + q];
+        if (mask && !(mask[(int64_t)r * mask_roi_stride + q] > 0.f)) v = 0.f;
+        return v;
+    }
+};
+struct EpiConv {       // y[r*roi_stride + co*49 + p] = act(v + bias[co])
+    float* y; int64_t roi_stride; const float* bias; int relu;
+    __device__ __forceinline__ void operator()(int, int m, int n, float v, bool) const {
+        int r = n / 49, p = n - r * 49;
+        if (bias) v += bias[m];
+        if (relu) v = fmaxf(v, 0.f);
+        y[(int64_t)r * roi_stride + m * 49 + p] = v;
+    }
+};
+struct WgradA {        // A(m=co, k=(r,p)) = dy[r*roi_stride + co*49 + p] * [relu_out > 0]
+    const float* dy; const float* mask; int64_t roi_stride; int Cout, K;
+    static constexpr bool kfast = true;
+    __device__ __forceinline__ float operator()(int, int, int m, int k) const {
+        if (m >= Cout || k >= K) return 0.f;
+        int r = k / 49, p = k - r * 49;
+        int64_t o = (int64_t)r * roi_stride + m * 49 + p;
+        float v = dy[o];
+        if (mask && !(mask[o] > 0.f)) v = 0.f;
+        return v;
+    }
+};
+struct WgradB {        // B(n=ci, k=(r,p)) for tap z: x[r*roi_stride + ci*49 + shift(p, tap)]
+    const float* x; int64_t roi_stride; int Cin, K;
+    static constexpr bool kfast = true;
+    __device__ __forceinline__ float operator()(int z, int, int n, int k) const {
+        if (n >= Cin || k >= K) return 0.f;
+        int r = k / 49, p = k - r * 49;
+        int py = p / 7, px = p - py * 7;
+        int yy = py + z / 3 - 1, xx = px + z % 3 - 1;
+        if ((unsigned)yy >= 7u || (unsigned)xx >= 7u) return 0.f;
+        return x[(int64_t)r * roi_stride + n * 49 + yy * 7 + xx];
+    }
+};
+
+// w [Cout,Cin,3,3] -> wp[tap][co][ci] (fwd) or wd[tap][ci][co] = w[co][ci][8-tap] (transposed + flipped, dgrad)
+__global__ void conv_w_permute_kernel(const float* __restrict__ w, float* __restrict__ wp, float* __restrict__ wd, int C) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int total = C * C * 9;
+    if (i >= total) return;
+    int tap = i / (C * C), rem = i - tap * C * C;
+    int a = rem / C, b = rem - a * C;
+    wp[i] = w[((int64_t)a * C + b) * 9 + tap];           // wp[tap][co=a][ci=b]
+    wd[i] = w[((int64_t)b * C + a) * 9 + (8 - tap)];     // wd[tap][ci=a][co=b]
+}
+// dwp[tap][co][ci] -> dw[co][ci][tap]
+__global__ void conv_dw_unpermute_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int C) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int total = C * C * 9;
+    if (i >= total) return;
+    int pair = i / 9, tap = i - pair * 9;
+    dw[i] = dwp[(int64_t)tap * C * C + pair];
+}
+
+// ---- reductions for bias gradients ---------------------------------------------------------------------
+// out[mid] = sum_{o, i} x[o*outer_stride + mid*inner + i] * [mask > 0]; one workgroup per (mid, outer chunk).
+__global__ void reduce_mid_kernel(const float* __restrict__ x, const float* __restrict__ mask, float* __restrict__ out,
+                                  int outer, int64_t outer_stride, int inner, int outer_chunk) {
+    int mid = blockIdx.x;
+    int o0 = blockIdx.y * outer_chunk;
+    int o1 = o0 + outer_chunk < outer ? o0 + outer_chunk : outer;
+    float s = 0.f;
+    for (int o = o0; o < o1; ++o) {
+        const float* row = x + (int64_t)o * outer_stride + (int64_t)mid * inner;
+        const float* mrow = mask ? mask + (int64_t)o * outer_stride + (int64_t)mid * inner : nullptr;
+        for (int i = threadIdx.x; i < inner; i += blockDim.x) {
+            float v = row[i];
+            if (mrow && !(mrow[i] > 0.f)) v = 0.f;
+            s += v;
+        }
+    }
+    s = wave_sum(s);
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += part[i];
+        unsafeAtomicAdd(out + mid, t);
+    }
+}
+// column sums of a row-major [rows, cols] matrix (inner == 1 case): threads along cols, rows chunked
+__global__ void colsum_kernel(const float* __restrict__ x, const float* __restrict__ mask, float* __restrict__ out,
+                              int rows, int cols, int row_chunk) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    int r0 = blockIdx.y * row_chunk;
+    int r1 = r0 + row_chunk < rows ? r0 + row_chunk : rows;
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) {
+        float v = x[(int64_t)r * cols + c];
+        if (mask && !(mask[(int64_t)r * cols + c] > 0.f)) v = 0.f;
+        s += v;
+    }
+    unsafeAtomicAdd(out + c, s);
+}
+
+// ---- NonLocal helpers ------------------------------------------------------------------------------------
+// wcat = [Wt;Wp;Wg] (3C x C), bcat = [bt;bp;bg]
+__global__ void nl_pack_kernel(const float* __restrict__ wt, const float* __restrict__ wp, const float* __restrict__ wg,
+                               const float* __restrict__ bt, const float* __restrict__ bp, const float* __restrict__ bg,
+                               float* __restrict__ wcat, float* __restrict__ bcat, int C) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int cc = C * C;
+    if (i < 3 * cc) {
+        int which = i / cc, j = i - which * cc;
+        wcat[i] = which == 0 ? wt[j] : (which == 1 ? wp[j] : wg[j]);
+    }
+    if (bcat && i < 3 * C) {
+        int which = i / C, j = i - which * C;
+        bcat[i] = which == 0 ? bt[j] : (which == 1 ? bp[j] : bg[j]);
+    }
+}
+__global__ void nl_unpack_kernel(const float* __restrict__ dwcat, const float* __restrict__ dbcat, float* __restrict__ dwt,
+                                 float* __restrict__ dwp, float* __restrict__ dwg, float* __restrict__ dbt,
+                                 float* __restrict__ dbp, float* __restrict__ dbg, int C) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int cc = C * C;
+    if (i < 3 * cc) {
+        int which = i / cc, j = i - which * cc;
+        float v = dwcat[i];
+        if (which == 0) dwt[j] = v; else if (which == 1) dwp[j] = v; else dwg[j] = v;
+    }
+    if (i < 3 * C) {
+        int which = i / C, j = i - which * C;
+        float v = dbcat[i];
+        if (which == 0) dbt[j] = v; else if (which == 1) dbp[j] = v; else dbg[j] = v;
+    }
+}
+
+// in-place row softmax of S [rows, L]: one 256-thread workgroup per row, the row is held in registers
+// (L <= 256*NL_ROW_REGS) so HBM sees one read and one write per element.
+constexpr int NL_ROW_REGS = 20;   // up to 5120 columns
+__global__ __launch_bounds__(256) void nl_softmax_rows_kernel(float* __restrict__ S, int L) {
+    float* row = S + (int64_t)blockIdx.x * L;
+    float v[NL_ROW_REGS];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NL_ROW_REGS; ++i) {
+        int j = threadIdx.x + i * 256;
+        v[i] = j < L ? row[j] : -INFINITY;
+        mx = fmaxf(mx, v[i]);
+    }
+    __shared__ float red[4];
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NL_ROW_REGS; ++i) {
+        int j = threadIdx.x + i * 256;
+        v[i] = j < L ? expf(v[i] - mx) : 0.f;
+        s += v[i];
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    s = (red[0] + red[1]) + (red[2] + red[3]);
+    float inv = 1.f / s;
+#pragma unroll
+    for (int i = 0; i < NL_ROW_REGS; ++i) {
+        int j = threadIdx.x + i * 256;
+        if (j < L) row[j] = v[i] * inv;
+    }
+}
+// dS = P * (dP - sum_j P dP), in place over dP
+__global__ __launch_bounds__(256) void nl_softmax_bwd_rows_kernel(const float* __restrict__ P, float* __restrict__ dP, int L) {
+    const float* prow = P + (int64_t)blockIdx.x * L;
+    float* drow = dP + (int64_t)blockIdx.x * L;
+    float p[NL_ROW_REGS], g[NL_ROW_REGS];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NL_ROW_REGS; ++i) {
+        int j = threadIdx.x + i * 256;
+        p[i] = j < L ? prow[j] : 0.f;
+        g[i] = j < L ? drow[j] : 0.f;
+        s += p[i] * g[i];
+    }
+    __shared__ float red[4];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    s = (red[0] + red[1]) + (red[2] + red[3]);
+#pragma unroll
+    for (int i = 0; i < NL_ROW_REGS; ++i) {
+        int j = threadIdx.x + i * 256;
+        if (j < L) drow[j] = p[i] * (g[i] - s);
+    }
+}
+
+__global__ void relu_inplace_kernel(float* __restrict__ x, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) x[i] = fmaxf(x[i], 0.f);
+}
+
+static inline EpiPlain epi_plain(float* c, int64_t sz, int64_t ld) {
+    EpiPlain e;
+    e.c = c; e.sz = sz; e.ld = ld; e.bias_m = nullptr; e.bias_n = nullptr; e.residual = nullptr;
+    e.relu = 0; e.accumulate = 0; e.atomic = 0;
+    return e;
+}
+
+// GEMM whose output region (zero_elems floats from e.c) may be cut along K when the tile count alone cannot
+// fill the chip: the output is zeroed and the slices add atomically (bias/residual enter with slice 0).
+template <class LA, class LB>
+static inline int32_t gemm_autosplit(int M, int N, int K, int kb, int batch, LA la, LB lb, EpiPlain e,
+                                     size_t zero_elems, hipStream_t st) {
+    int splitk = (e.relu || e.accumulate) ? 1 : pick_splitk(M, N, batch, (kb < 1 ? 1 : kb) * cdiv(K, GEMM_BK));
+    if (splitk > 1) {
+        if (hipMemsetAsync(e.c, 0, sizeof(float) * zero_elems, st) != hipSuccess) {
+            set_error("gemm: memset failed");
+            return ARFE_ERR_LAUNCH;
+        }
+        e.atomic = 1;
+    }
+    return launch_gemm(M, N, K, kb, batch, splitk, la, lb, e, st);
+}
+
+}  // namespace arfe
+
+using namespace arfe;
+
+// =========================================================================================================
+// nn.Linear
+// =========================================================================================================
+extern "C" int32_t arfe_linear_fwd(int32_t R, int32_t in_f, int32_t out_f, const float* x, const float* w,
+                                   const float* b, int32_t relu, float* y, void* stream) {
+    ARFE_CHECK_ARG(R >= 0 && in_f > 0 && out_f > 0, ARFE_ERR_ARG, "linear_fwd: bad shape R=%d in=%d out=%d", R, in_f, out_f);
+    if (R == 0) return ARFE_OK;
+    ARFE_CHECK_ARG(x && w && y, ARFE_ERR_ARG, "linear_fwd: null pointer");
+    hipStream_t st = as_stream(stream);
+    // y[R,out] = x[R,in] . w[out,in]^T : A = x (k contiguous), B(n,k) = w[n*in + k] (k contiguous)
+    LoadRowMajorK la{x, 0, 0, in_f, R, in_f};
+    LoadRowMajorK lb{w, 0, 0, in_f, out_f, in_f};
+    int ksteps = cdiv(in_f, GEMM_BK);
+    int splitk = pick_splitk(R, out_f, 1, ksteps);
+    EpiPlain e = epi_plain(y, 0, out_f);
+    e.bias_n = b;
+    if (splitk > 1) {
+        // split-K: atomic partial sums into a zeroed output, activation in a second tiny pass
+        if (hipMemsetAsync(y, 0, sizeof(float) * (size_t)R * out_f, st) != hipSuccess) {
+            set_error("linear_fwd: memset failed");
+            return ARFE_ERR_LAUNCH;
+        }
+        e.atomic = 1;
+        int32_t rc = launch_gemm(R, out_f, in_f, 1, 1, splitk, la, lb, e, st);
+        if (rc) return rc;
+        if (relu) {
+            int64_t n = (int64_t)R * out_f;
+            hipLaunchKernelGGL(relu_inplace_kernel, dim3((unsigned)(n / 256 + 1 < 4096 ? n / 256 + 1 : 4096)), dim3(256), 0, st, y, n);
+            ARFE_CHECK_LAUNCH();
+        }
+        return ARFE_OK;
+    }
+    e.relu = relu;
+    return launch_gemm(R, out_f, in_f, 1, 1, 1, la, lb, e, st);
+}
+
+extern "C" int32_t arfe_linear_bwd(int32_t R, int32_t in_f, int32_t out_f, const float* x, const float* w,
+                                   const float* dy, const float* relu_out, float* dx, int32_t accumulate_dx,
+                                   float* dw, float* db, void* stream) {
+    ARFE_CHECK_ARG(R >= 0 && in_f > 0 && out_f > 0, ARFE_ERR_ARG, "linear_bwd: bad shape");
+    hipStream_t st = as_stream(stream);
+    if (dw && hipMemsetAsync(dw, 0, sizeof(float) * (size_t)out_f * in_f, st) != hipSuccess) return ARFE_ERR_LAUNCH;
+    if (db && hipMemsetAsync(db, 0, sizeof(float) * (size_t)out_f, st) != hipSuccess) return ARFE_ERR_LAUNCH;
+    if (R == 0) {
+        if (dx && !accumulate_dx) return ARFE_OK;
+        return ARFE_OK;
+    }
+    ARFE_CHECK_ARG(x && w && dy, ARFE_ERR_ARG, "linear_bwd: null pointer");
+    int32_t rc;
+    if (dx) {
+        // dx[R,in] = dy_eff[R,out] . w[out,in] : A = dy (k=out contiguous, masked), B(n=in,k=out) = w[k*in + n]
+        LoadMaskedK la{dy, relu_out, out_f, R, out_f};
+        LoadRowMajorI lb{w, 0, 0, in_f, in_f, out_f};
+        int splitk = pick_splitk(R, in_f, 1, cdiv(out_f, GEMM_BK));
+        EpiPlain e = epi_plain(dx, 0, in_f);
+        if (splitk > 1) {
+            if (!accumulate_dx && hipMemsetAsync(dx, 0, sizeof(float) * (size_t)R * in_f, st) != hipSuccess)
+                return ARFE_ERR_LAUNCH;
+            e.atomic = 1;
+        } else {
+            e.accumulate = accumulate_dx;
+        }
+        rc = launch_gemm(R, in_f, out_f, 1, 1, splitk, la, lb, e, st);
+        if (rc) return rc;
+    }
+    if (dw) {
+        // dw[out,in] = dy_eff^T[out,R] . x[R,in] : A(m=out,k=r) = dy[k*out + m] (m contiguous), B(n=in,k=r) = x[k*in+n]
+        LoadMaskedI la{dy, relu_out, out_f, out_f, R};
+        LoadRowMajorI lb{x, 0, 0, in_f, in_f, R};
+        int splitk = pick_splitk(out_f, in_f, 1, cdiv(R, GEMM_BK));
+        EpiPlain e = epi_plain(dw, 0, in_f);
+        e.atomic = splitk > 1;
+        rc = launch_gemm(out_f, in_f, R, 1, 1, splitk, la, lb, e, st);
+        if (rc) return rc;
+    }
+    if (db) {
+        int chunk = 64;
+        dim3 grid(cdiv(out_f, 256), cdiv(R, chunk));
+        hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, st, dy, relu_out, db, R, out_f, chunk);
+        ARFE_CHECK_LAUNCH();
+    }
+    return ARFE_OK;
+}
+
+// =========================================================================================================
+// 3x3 conv on RoI tiles
+// =========================================================================================================
+extern "C" int64_t arfe_conv3x3_workspace_bytes(int32_t C) {
+    // wp + wd (permuted weights) + dwp (permuted weight gradient)
+    return (int64_t)3 * 9 * C * C * sizeof(float);
+}
+
+extern "C" int32_t arfe_conv3x3_fwd(int32_t R, int32_t C, const float* x, int64_t x_roi_stride, const float* w,
+                                    const float* b, int32_t relu, float* y, int64_t y_roi_stride, void* workspace,
+                                    void* stream) {
+    ARFE_CHECK_ARG(R >= 0 && C > 0, ARFE_ERR_ARG, "conv3x3_fwd: bad shape");
+    if (R == 0) return ARFE_OK;
+    ARFE_CHECK_ARG(x && w && y && workspace, ARFE_ERR_ARG, "conv3x3_fwd: null pointer");
+    hipStream_t st = as_stream(stream);
+    float* wp = (float*)workspace;
+    float* wd = wp + (size_t)9 * C * C;
+    int total = 9 * C * C;
+    hipLaunchKernelGGL(conv_w_permute_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, w, wp, wd, C);
+    ARFE_CHECK_LAUNCH();
+    LoadRowMajorK la{wp, 0, (int64_t)C * C, C, C, C};     // A(m=co,k=ci) for tap kb
+    ConvGatherB lb{x, nullptr, x_roi_stride, 0, R * 49, C};
+    EpiConv e{y, y_roi_stride, b, relu};
+    return launch_gemm(C, R * 49, C, 9, 1, 1, la, lb, e, st);
+}
+
+extern "C" int32_t arfe_conv3x3_bwd(int32_t R, int32_t C, const float* x, int64_t x_roi_stride, const float* w,
+                                    const float* dy, const float* relu_out, int64_t dy_roi_stride, float* dx,
+                                    int64_t dx_roi_stride, float* dw, float* db, void* workspace, void* stream) {
+    ARFE_CHECK_ARG(R >= 0 && C > 0, ARFE_ERR_ARG, "conv3x3_bwd: bad shape");
+    hipStream_t st = as_stream(stream);
+    if (dw && hipMemsetAsync(dw, 0, sizeof(float) * (size_t)9 * C * C, st) != hipSuccess) return ARFE_ERR_LAUNCH;
+    if (db && hipMemsetAsync(db, 0, sizeof(float) * (size_t)C, st) != hipSuccess) return ARFE_ERR_LAUNCH;
+    if (R == 0) return ARFE_OK;
+    ARFE_CHECK_ARG(x && w && dy && workspace, ARFE_ERR_ARG, "conv3x3_bwd: null pointer");
+    float* wp = (float*)workspace;
+    float* wd = wp + (size_t)9 * C * C;
+    float* dwp = wd + (size_t)9 * C * C;
+    int total = 9 * C * C;
+    int32_t rc;
+    if (dx) {
+        hipLaunchKernelGGL(conv_w_permute_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, w, wp, wd, C);
+        ARFE_CHECK_LAUNCH();
+        LoadRowMajorK la{wd, 0, (int64_t)C * C, C, C, C};  // A(m=ci,k=co) = w[co][ci][8-tap]
+        ConvGatherB lb{dy, relu_out, dy_roi_stride, dy_roi_stride, R * 49, C};
+        EpiConv e{dx, dx_roi_stride, nullptr, 0};
+        rc = launch_gemm(C, R * 49, C, 9, 1, 1, la, lb, e, st);
+        if (rc) return rc;
+    }
+    if (dw) {
+        if (hipMemsetAsync(dwp, 0, sizeof(float) * (size_t)total, st) != hipSuccess) return ARFE_ERR_LAUNCH;
+        WgradA la{dy, relu_out, dy_roi_stride, C, R * 49};
+        WgradB lb{x, x_roi_stride, C, R * 49};
+        int ksteps = cdiv(R * 49, GEMM_BK);
+        int splitk = pick_splitk(C, C, 9, ksteps);
+        EpiPlain e = epi_plain(dwp, (int64_t)C * C, C);
+        e.atomic = 1;
+        rc = launch_gemm(C, C, R * 49, 1, 9, splitk, la, lb, e, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(conv_dw_unpermute_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, dwp, dw, C);
+        ARFE_CHECK_LAUNCH();
+    }
+    if (db) {
+        int chunk = 32;
+        dim3 grid(C, cdiv(R, chunk));
+        hipLaunchKernelGGL(reduce_mid_kernel, grid, dim3(64), 0, st, dy, relu_out, db, R, dy_roi_stride, 49, chunk);
+        ARFE_CHECK_LAUNCH();
+    }
+    return ARFE_OK;
+}
+
+// =========================================================================================================
+// NonLocal2D
+// =========================================================================================================
+extern "C" int64_t arfe_nonlocal_workspace_bytes(int32_t B, int32_t C, int32_t L) {
+    // wcat (3C*C) + bcat (3C) + dwcat (3C*C) + dbcat (3C) + dtpg [B,3C,L] + dy [B,C,L]
+    int64_t f = (int64_t)2 * (3 * C * C + 3 * C) + (int64_t)B * 3 * C * L + (int64_t)B * C * L;
+    return f * (int64_t)sizeof(float) + 256;
+}
+
+extern "C" int32_t arfe_nonlocal_fwd(int32_t B, int32_t C, int32_t L, const float* m, const float* w_theta,
+                                     const float* b_theta, const float* w_phi, const float* b_phi, const float* w_g,
+                                     const float* b_g, const float* w_out, const float* b_out, float* tpg, float* P,
+                                     float* y, float* bsf, void* workspace, void* stream) {
+    ARFE_CHECK_ARG(B > 0 && C > 0 && L > 0, ARFE_ERR_ARG, "nonlocal_fwd: bad shape B=%d C=%d L=%d", B, C, L);
+    ARFE_CHECK_ARG(L <= 256 * NL_ROW_REGS, ARFE_ERR_ARG, "nonlocal_fwd: L=%d exceeds the row-softmax limit %d", L,
+                   256 * NL_ROW_REGS);
+    ARFE_CHECK_ARG(m && w_theta && w_phi && w_g && w_out && tpg && P && y && bsf && workspace, ARFE_ERR_ARG,
+                   "nonlocal_fwd: null pointer");
+    hipStream_t st = as_stream(stream);
+    float* wcat = (float*)workspace;
+    float* bcat = wcat + (size_t)3 * C * C;
+    hipLaunchKernelGGL(nl_pack_kernel, dim3(cdiv(3 * C * C, 256)), dim3(256), 0, st, w_theta, w_phi, w_g, b_theta,
+                       b_phi, b_g, wcat, bcat, C);
+    ARFE_CHECK_LAUNCH();
+    const int64_t CL = (int64_t)C * L, LL = (int64_t)L * L;
+    int32_t rc;
+    {   // tpg[z] [3C,L] = wcat [3C,C] . m[z] [C,L] + bcat
+        LoadRowMajorK la{wcat, 0, 0, C, 3 * C, C};
+        LoadRowMajorI lb{m, CL, 0, L, L, C};
+        EpiPlain e = epi_plain(tpg, 3 * CL, L);
+        e.bias_m = bcat;
+        rc = launch_gemm(3 * C, L, C, 1, B, 1, la, lb, e, st);
+        if (rc) return rc;
+    }
+    {   // S[z][i][j] = sum_c theta[c][i] phi[c][j]
+        LoadRowMajorI la{tpg, 3 * CL, 0, L, L, C};
+        LoadRowMajorI lb{tpg + CL, 3 * CL, 0, L, L, C};
+        EpiPlain e = epi_plain(P, LL, L);
+        rc = launch_gemm(L, L, C, 1, B, 1, la, lb, e, st);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(nl_softmax_rows_kernel, dim3(B * L), dim3(256), 0, st, P, L);
+    ARFE_CHECK_LAUNCH();
+    {   // y[z][c][i] = sum_j g[c][j] P[i][j]
+        LoadRowMajorK la{tpg + 2 * CL, 3 * CL, 0, L, C, L};
+        LoadRowMajorK lb{P, LL, 0, L, L, L};
+        EpiPlain e = epi_plain(y, CL, L);
+        rc = gemm_autosplit(C, L, L, 1, B, la, lb, e, (size_t)B * CL, st);
+        if (rc) return rc;
+    }
+    {   // bsf[z] = m[z] + w_out . y[z] + b_out
+        LoadRowMajorK la{w_out, 0, 0, C, C, C};
+        LoadRowMajorI lb{y, CL, 0, L, L, C};
+        EpiPlain e = epi_plain(bsf, CL, L);
+        e.bias_m = b_out;
+        e.residual = m;
+        rc = launch_gemm(C, L, C, 1, B, 1, la, lb, e, st);
+        if (rc) return rc;
+    }
+    return ARFE_OK;
+}
+
+extern "C" int32_t arfe_nonlocal_bwd(int32_t B, int32_t C, int32_t L, const float* dbsf, const float* m,
+                                     const float* w_theta, const float* w_phi, const float* w_g, const float* w_out,
+                                     const float* tpg, const float* P, const float* y, float* dP, float* dm,
+                                     float* dw_theta, float* db_theta, float* dw_phi, float* db_phi, float* dw_g,
+                                     float* db_g, float* dw_out, float* db_out, void* workspace, void* stream) {
+    ARFE_CHECK_ARG(B > 0 && C > 0 && L > 0 && L <= 256 * NL_ROW_REGS, ARFE_ERR_ARG, "nonlocal_bwd: bad shape");
+    ARFE_CHECK_ARG(dbsf && m && w_theta && w_phi && w_g && w_out && tpg && P && y && dP && dm && dw_theta && db_theta &&
+                       dw_phi && db_phi && dw_g && db_g && dw_out && db_out && workspace,
+                   ARFE_ERR_ARG, "nonlocal_bwd: null pointer");
+    hipStream_t st = as_stream(stream);
+    const int64_t CL = (int64_t)C * L, LL = (int64_t)L * L;
+    float* wcat = (float*)workspace;
+    float* bcat = wcat + (size_t)3 * C * C;
+    float* dwcat = bcat + (size_t)3 * C;
+    float* dbcat = dwcat + (size_t)3 * C * C;
+    float* dtpg = dbcat + (size_t)3 * C;
+    float* dy = dtpg + (size_t)B * 3 * CL;
+    hipLaunchKernelGGL(nl_pack_kernel, dim3(cdiv(3 * C * C, 256)), dim3(256), 0, st, w_theta, w_phi, w_g,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, wcat, (float*)nullptr, C);
+    ARFE_CHECK_LAUNCH();
+    if (hipMemsetAsync(dwcat, 0, sizeof(float) * ((size_t)3 * C * C + 3 * C), st) != hipSuccess) return ARFE_ERR_LAUNCH;
+    if (hipMemsetAsync(dtpg, 0, sizeof(float) * (size_t)B * 3 * CL, st) != hipSuccess) return ARFE_ERR_LAUNCH;
+    if (hipMemsetAsync(dw_out, 0, sizeof(float) * (size_t)C * C, st) != hipSuccess) return ARFE_ERR_LAUNCH;
+    if (hipMemsetAsync(db_out, 0, sizeof(float) * (size_t)C, st) != hipSuccess) return ARFE_ERR_LAUNCH;
+    int32_t rc;
+    const int kstepsL = cdiv(L, GEMM_BK);
+    {   // dw_out[co][ci] = sum_{z,l} dbsf[z][co][l] y[z][ci][l]   (k-batched over images, split-K)
+        LoadRowMajorK la{dbsf, 0, CL, L, C, L};
+        LoadRowMajorK lb{y, 0, CL, L, C, L};
+        EpiPlain e = epi_plain(dw_out, 0, C);
+        e.atomic = 1;
+        rc = launch_gemm(C, C, L, B, 1, pick_splitk(C, C, 1, B * kstepsL), la, lb, e, st);
+        if (rc) return rc;
+        dim3 grid(C, B);
+        hipLaunchKernelGGL(reduce_mid_kernel, grid, dim3(256), 0, st, dbsf, (const float*)nullptr, db_out, B, CL, L, 1);
+        ARFE_CHECK_LAUNCH();
+    }
+    {   // dy[z][ci][l] = sum_co w_out[co][ci] dbsf[z][co][l]
+        LoadRowMajorI la{w_out, 0, 0, C, C, C};
+        LoadRowMajorI lb{dbsf, CL, 0, L, L, C};
+        EpiPlain e = epi_plain(dy, CL, L);
+        rc = launch_gemm(C, L, C, 1, B, 1, la, lb, e, st);
+        if (rc) return rc;
+    }
+    {   // dP[z][i][j] = sum_c dy[c][i] g[c][j]
+        LoadRowMajorI la{dy, CL, 0, L, L, C};
+        LoadRowMajorI lb{tpg + 2 * CL, 3 * CL, 0, L, L, C};
+        EpiPlain e = epi_plain(dP, LL, L);
+        rc = launch_gemm(L, L, C, 1, B, 1, la, lb, e, st);
+        if (rc) return rc;
+    }
+    {   // dg[z][c][j] = sum_i dy[c][i] P[i][j]   (before dP is overwritten nothing depends on order; P is read-only)
+        LoadRowMajorK la{dy, CL, 0, L, C, L};
+        LoadRowMajorI lb{P, LL, 0, L, L, L};
+        EpiPlain e = epi_plain(dtpg + 2 * CL, 3 * CL, L);
+        rc = gemm_autosplit(C, L, L, 1, B, la, lb, e, 0, st);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(nl_softmax_bwd_rows_kernel, dim3(B * L), dim3(256), 0, st, P, dP, L);   // dP <- dS
+    ARFE_CHECK_LAUNCH();
+    {   // dtheta[z][c][i] = sum_j dS[i][j] phi[c][j]
+        LoadRowMajorK la{tpg + CL, 3 * CL, 0, L, C, L};
+        LoadRowMajorK lb{dP, LL, 0, L, L, L};
+        EpiPlain e = epi_plain(dtpg, 3 * CL, L);
+        rc = gemm_autosplit(C, L, L, 1, B, la, lb, e, 0, st);
+        if (rc) return rc;
+    }
+    {   // dphi[z][c][j] = sum_i dS[i][j] theta[c][i]
+        LoadRowMajorK la{tpg, 3 * CL, 0, L, C, L};
+        LoadRowMajorI lb{dP, LL, 0, L, L, L};
+        EpiPlain e = epi_plain(dtpg + CL, 3 * CL, L);
+        rc = gemm_autosplit(C, L, L, 1, B, la, lb, e, 0, st);
+        if (rc) return rc;
+    }
+    {   // dm[z] = dbsf[z] + wcat^T . dtpg[z]
+        LoadRowMajorI la{wcat, 0, 0, C, C, 3 * C};
+        LoadRowMajorI lb{dtpg, 3 * CL, 0, L, L, 3 * C};
+        EpiPlain e = epi_plain(dm, CL, L);
+        e.residual = dbsf;
+        rc = gemm_autosplit(C, L, 3 * C, 1, B, la, lb, e, (size_t)B * CL, st);
+        if (rc) return rc;
+    }
+    {   // dwcat[3C][C] = sum_{z,l} dtpg[z][.][l] m[z][.][l] ; dbcat = rowsum(dtpg)
+        LoadRowMajorK la{dtpg, 0, 3 * CL, L, 3 * C, L};
+        LoadRowMajorK lb{m, 0, CL, L, C, L};
+        EpiPlain e = epi_plain(dwcat, 0, C);
+        e.atomic = 1;
+        rc = launch_gemm(3 * C, C, L, B, 1, pick_splitk(3 * C, C, 1, B * kstepsL), la, lb, e, st);
+        if (rc) return rc;
+        dim3 grid(3 * C, B);
+        hipLaunchKernelGGL(reduce_mid_kernel, grid, dim3(256), 0, st, dtpg, (const float*)nullptr, dbcat, B, 3 * CL, L, 1);
+        ARFE_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(nl_unpack_kernel, dim3(cdiv(3 * C * C, 256)), dim3(256), 0, st, dwcat, dbcat, dw_theta, dw_phi, dw_g,
+                       db_theta, db_phi, db_g, C);
+    ARFE_CHECK_LAUNCH();
+    return ARFE_OK;
+}

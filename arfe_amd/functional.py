@@ -1,0 +1,362 @@
+"""Thin host-side wrappers over the C ABI (device memory, streams and autograd plumbing only).
+
+Raw ops (`*_op`) allocate outputs/workspaces with torch and call libarfe_hip; the three
+`torch.autograd.Function`s wire them into AR-FPN, the 3-RoI extractor and the AR-RFF head.
+Nothing here computes on the CPU or through PyTorch kernels.
+"""
+import ctypes
+
+import torch
+
+from . import hip
+from .hip import Pyramid, check, ptr, ptr_array, stream
+
+_i32 = ctypes.c_int32
+
+
+def _empty_like_levels(xs):
+    return [torch.empty_like(x) for x in xs]
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# AR-FPN raw ops
+# ---------------------------------------------------------------------------------------------------------
+
+def fpn_gather_op(xs, refine_level, want_argmax=True):
+    hip.require_f32_cuda(*xs)
+    pyr = Pyramid.of(xs, refine_level)
+    B, C = xs[0].shape[:2]
+    hr, wr = xs[refine_level].shape[2:]
+    m = torch.empty(B, C, hr, wr, device=xs[0].device)
+    argmax = None
+    if want_argmax and refine_level > 0:
+        argmax = torch.empty(refine_level, B, C, hr, wr, dtype=torch.int32, device=xs[0].device)
+    check(hip.lib().arfe_fpn_gather_fwd(ctypes.byref(pyr), ptr_array(xs), ptr(m), ptr(argmax), stream()),
+          "arfe_fpn_gather_fwd")
+    return m, argmax
+
+
+def fpn_gatemap_op(xs, w1, b1, w2, b2, refine_level=0):
+    hip.require_f32_cuda(*xs, *w1, *b1, *w2, *b2)
+    pyr = Pyramid.of(xs, refine_level)
+    dev = xs[0].device
+    a = [torch.empty(x.shape[0], 1, x.shape[2], x.shape[3], device=dev) for x in xs]
+    b = [torch.empty(x.shape[0], 1, x.shape[2], x.shape[3], device=dev) for x in xs]
+    ws = _ws(hip.lib().arfe_fpn_gatemap_workspace_bytes(ctypes.byref(pyr)), dev)
+    check(hip.lib().arfe_fpn_gatemap_fwd(ctypes.byref(pyr), ptr_array(xs), ptr_array(w1), ptr_array(b1),
+                                         ptr_array(w2), ptr_array(b2), ptr_array(a), ptr_array(b), ptr(ws),
+                                         stream()), "arfe_fpn_gatemap_fwd")
+    return a, b
+
+
+def fpn_scatter_op(xs, bsf, a, b, refine_level):
+    hip.require_f32_cuda(*xs, bsf, *a, *b)
+    pyr = Pyramid.of(xs, refine_level)
+    outs = _empty_like_levels(xs)
+    check(hip.lib().arfe_fpn_scatter_fwd(ctypes.byref(pyr), ptr_array(xs), ptr(bsf), ptr_array(a), ptr_array(b),
+                                         ptr_array(outs), stream()), "arfe_fpn_scatter_fwd")
+    return outs
+
+
+def fpn_scatter_bwd_op(gouts, bsf, a, b, refine_level):
+    hip.require_f32_cuda(*gouts, bsf, *a, *b)
+    pyr = Pyramid.of(gouts, refine_level)
+    dpa = [torch.empty_like(t) for t in a]
+    dpb = [torch.empty_like(t) for t in b]
+    dbsf = torch.empty_like(bsf)
+    check(hip.lib().arfe_fpn_scatter_bwd(ctypes.byref(pyr), ptr_array(gouts), ptr(bsf), ptr_array(a), ptr_array(b),
+                                         ptr_array(dpa), ptr_array(dpb), ptr(dbsf), stream()),
+          "arfe_fpn_scatter_bwd")
+    return dpa, dpb, dbsf
+
+
+def fpn_input_bwd_op(gouts, dpa, dpb, w1, w2, dm, argmax, refine_level):
+    hip.require_f32_cuda(*gouts, *dpa, *dpb, *w1, *w2, dm)
+    pyr = Pyramid.of(gouts, refine_level)
+    dxs = _empty_like_levels(gouts)
+    check(hip.lib().arfe_fpn_input_bwd(ctypes.byref(pyr), ptr_array(gouts), ptr_array(dpa), ptr_array(dpb),
+                                       ptr_array(w1), ptr_array(w2), ptr(dm), ptr(argmax), ptr_array(dxs),
+                                       stream()), "arfe_fpn_input_bwd")
+    return dxs
+
+
+def fpn_gate_wgrad_op(xs, dpa, dpb, refine_level=0):
+    hip.require_f32_cuda(*xs, *dpa, *dpb)
+    pyr = Pyramid.of(xs, refine_level)
+    dev, C = xs[0].device, xs[0].shape[1]
+    n = len(xs)
+    dw1 = [torch.empty(1, C, 3, 3, device=dev) for _ in range(n)]
+    dw2 = [torch.empty(1, C, 3, 3, device=dev) for _ in range(n)]
+    db1 = [torch.empty(1, device=dev) for _ in range(n)]
+    db2 = [torch.empty(1, device=dev) for _ in range(n)]
+    check(hip.lib().arfe_fpn_gate_wgrad(ctypes.byref(pyr), ptr_array(xs), ptr_array(dpa), ptr_array(dpb),
+                                        ptr_array(dw1), ptr_array(db1), ptr_array(dw2), ptr_array(db2), stream()),
+          "arfe_fpn_gate_wgrad")
+    return dw1, db1, dw2, db2
+
+
+# ---------------------------------------------------------------------------------------------------------
+# NonLocal2D raw ops
+# ---------------------------------------------------------------------------------------------------------
+
+def nonlocal_fwd_op(m, wt, bt, wp, bp, wg, bg, wo, bo):
+    hip.require_f32_cuda(m, wt, bt, wp, bp, wg, bg, wo, bo)
+    B, C, h, w = m.shape
+    L = h * w
+    dev = m.device
+    tpg = torch.empty(B, 3 * C, L, device=dev)
+    P = torch.empty(B, L, L, device=dev)
+    y = torch.empty(B, C, L, device=dev)
+    bsf = torch.empty_like(m)
+    ws = _ws(hip.lib().arfe_nonlocal_workspace_bytes(B, C, L), dev)
+    check(hip.lib().arfe_nonlocal_fwd(B, C, L, ptr(m), ptr(wt), ptr(bt), ptr(wp), ptr(bp), ptr(wg), ptr(bg), ptr(wo),
+                                      ptr(bo), ptr(tpg), ptr(P), ptr(y), ptr(bsf), ptr(ws), stream()),
+          "arfe_nonlocal_fwd")
+    return bsf, (tpg, P, y)
+
+
+def nonlocal_bwd_op(dbsf, m, wt, wp, wg, wo, saved):
+    tpg, P, y = saved
+    hip.require_f32_cuda(dbsf, m, wt, wp, wg, wo, tpg, P, y)
+    B, C, h, w = m.shape
+    L = h * w
+    dev = m.device
+    dP = torch.empty_like(P)
+    dm = torch.empty_like(m)
+    dwt, dwp, dwg, dwo = (torch.empty_like(t) for t in (wt, wp, wg, wo))
+    dbt, dbp, dbg, dbo = (torch.empty(C, device=dev) for _ in range(4))
+    ws = _ws(hip.lib().arfe_nonlocal_workspace_bytes(B, C, L), dev)
+    check(hip.lib().arfe_nonlocal_bwd(B, C, L, ptr(dbsf), ptr(m), ptr(wt), ptr(wp), ptr(wg), ptr(wo), ptr(tpg), ptr(P),
+                                      ptr(y), ptr(dP), ptr(dm), ptr(dwt), ptr(dbt), ptr(dwp), ptr(dbp), ptr(dwg),
+                                      ptr(dbg), ptr(dwo), ptr(dbo), ptr(ws), stream()), "arfe_nonlocal_bwd")
+    return dm, (dwt, dbt, dwp, dbp, dwg, dbg, dwo, dbo)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# AR-FPN autograd
+# ---------------------------------------------------------------------------------------------------------
+
+class ARFPNFunction(torch.autograd.Function):
+    """WFPNDualSpatial.forward as one autograd node.
+    args: refine_level, n, x_0..x_{n-1}, w1_0.., b1_0.., w2_0.., b2_0.., wt, bt, wp, bp, wg, bg, wo, bo"""
+
+    @staticmethod
+    def forward(ctx, refine_level, n, *t):
+        xs = [v.contiguous() for v in t[0:n]]
+        w1, b1 = list(t[n:2 * n]), list(t[2 * n:3 * n])
+        w2, b2 = list(t[3 * n:4 * n]), list(t[4 * n:5 * n])
+        wt, bt, wp, bp, wg, bg, wo, bo = t[5 * n:5 * n + 8]
+        w1, b1, w2, b2 = ([v.contiguous() for v in l] for l in (w1, b1, w2, b2))
+        need_grad = any(ctx.needs_input_grad)
+        m, argmax = fpn_gather_op(xs, refine_level, want_argmax=need_grad)
+        bsf, saved = nonlocal_fwd_op(m, wt, bt, wp, bp, wg, bg, wo, bo)
+        a, b = fpn_gatemap_op(xs, w1, b1, w2, b2, refine_level)
+        outs = fpn_scatter_op(xs, bsf, a, b, refine_level)
+        ctx.refine_level, ctx.n = refine_level, n
+        if need_grad:
+            ctx.save_for_backward(*xs, *w1, *w2, wt, wp, wg, wo, m, bsf, *a, *b, *saved,
+                                  *( [argmax] if argmax is not None else []))
+            ctx.has_argmax = argmax is not None
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        n, r = ctx.n, ctx.refine_level
+        s = ctx.saved_tensors
+        xs, w1, w2 = list(s[0:n]), list(s[n:2 * n]), list(s[2 * n:3 * n])
+        wt, wp, wg, wo, m, bsf = s[3 * n:3 * n + 6]
+        a, b = list(s[3 * n + 6:4 * n + 6]), list(s[4 * n + 6:5 * n + 6])
+        saved = s[5 * n + 6:5 * n + 9]
+        argmax = s[5 * n + 9] if ctx.has_argmax else None
+        gouts = [g.contiguous() if g is not None else torch.zeros_like(x) for g, x in zip(gouts, xs)]
+        dpa, dpb, dbsf = fpn_scatter_bwd_op(gouts, bsf, a, b, r)
+        dm, (dwt, dbt, dwp, dbp, dwg, dbg, dwo, dbo) = nonlocal_bwd_op(dbsf, m, wt, wp, wg, wo, saved)
+        dxs = fpn_input_bwd_op(gouts, dpa, dpb, w1, w2, dm, argmax, r)
+        dw1, db1, dw2, db2 = fpn_gate_wgrad_op(xs, dpa, dpb, r)
+        return (None, None, *dxs, *dw1, *db1, *dw2, *db2, dwt, dbt, dwp, dbp, dwg, dbg, dwo, dbo)
+
+
+def arfpn(xs, w1, b1, w2, b2, wt, bt, wp, bp, wg, bg, wo, bo, refine_level=2):
+    n = len(xs)
+    return ARFPNFunction.apply(refine_level, n, *xs, *w1, *b1, *w2, *b2, wt, bt, wp, bp, wg, bg, wo, bo)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# AR-RFF RoI side
+# ---------------------------------------------------------------------------------------------------------
+
+def make_rois_op(rois):
+    hip.require_f32_cuda(rois)
+    h_rois, w_rois = torch.empty_like(rois), torch.empty_like(rois)
+    check(hip.lib().arfe_rff_make_rois(rois.shape[0], ptr(rois), ptr(h_rois), ptr(w_rois), stream()),
+          "arfe_rff_make_rois")
+    return h_rois, w_rois
+
+
+def map_roi_levels_op(rois, num_levels, finest_scale=56):
+    hip.require_f32_cuda(rois)
+    lv = torch.empty(rois.shape[0], dtype=torch.int64, device=rois.device)
+    check(hip.lib().arfe_map_roi_levels(rois.shape[0], ptr(rois), num_levels, float(finest_scale), ptr(lv), stream()),
+          "arfe_map_roi_levels")
+    return lv
+
+
+def _stride_array(strides):
+    arr = (_i32 * hip.MAX_LEVELS)()
+    for i, s in enumerate(strides):
+        arr[i] = int(s)
+    return arr
+
+
+def roialign_fwd_op(feats, strides, rois, levels, out, chan_offset, pooled=7, sample_num=0):
+    """Writes RoIAlign(feats[levels[k]], rois[k]) into out[:, chan_offset:chan_offset+C] in place."""
+    hip.require_f32_cuda(*feats, rois, out)
+    pyr = Pyramid.of(feats, 0)
+    view = out[:, chan_offset:]
+    check(hip.lib().arfe_roialign_fwd(ctypes.byref(pyr), ptr_array(feats), _stride_array(strides), rois.shape[0],
+                                      ptr(rois), ptr(levels), pooled, sample_num, view.data_ptr(), out.stride(0),
+                                      stream()), "arfe_roialign_fwd")
+
+
+def roialign_bwd_op(dfeats, strides, rois, levels, gout, chan_offset, pooled=7, sample_num=0):
+    pyr = Pyramid.of(dfeats, 0)
+    view = gout[:, chan_offset:]
+    check(hip.lib().arfe_roialign_bwd(ctypes.byref(pyr), ptr_array(dfeats), _stride_array(strides), rois.shape[0],
+                                      ptr(rois), ptr(levels), pooled, sample_num, view.data_ptr(), gout.stride(0),
+                                      stream()), "arfe_roialign_bwd")
+
+
+class RoIExtractFunction(torch.autograd.Function):
+    """SingleRoIExtractor.forward for `nsets` RoI sets at once; set s fills channels [s*C, (s+1)*C) of the
+    [R, nsets*C, P, P] output (the concat of standard_roi_head.py:155 without a copy).
+    args: strides, finest_scale, pooled, sample_num, nsets, rois_0..rois_{nsets-1}, feat_0..feat_{n-1}"""
+
+    @staticmethod
+    def forward(ctx, strides, finest_scale, pooled, sample_num, nsets, *t):
+        roi_sets = [r.contiguous() for r in t[:nsets]]
+        feats = [f.contiguous() for f in t[nsets:]]
+        R, C = roi_sets[0].shape[0], feats[0].shape[1]
+        out = torch.empty(R, nsets * C, pooled, pooled, device=feats[0].device)
+        levels = []
+        for s, rois in enumerate(roi_sets):
+            lv = map_roi_levels_op(rois, len(feats), finest_scale)
+            roialign_fwd_op(feats, strides, rois, lv, out, s * C, pooled, sample_num)
+            levels.append(lv)
+        ctx.cfg = (tuple(strides), pooled, sample_num, nsets, C)
+        ctx.shapes = [f.shape for f in feats]
+        ctx.save_for_backward(*roi_sets, *levels)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        strides, pooled, sample_num, nsets, C = ctx.cfg
+        s = ctx.saved_tensors
+        roi_sets, levels = s[:nsets], s[nsets:]
+        gout = gout.contiguous()
+        dfeats = [torch.zeros(shape, device=gout.device) for shape in ctx.shapes]
+        for k in range(nsets):
+            roialign_bwd_op(dfeats, strides, roi_sets[k], levels[k], gout, k * C, pooled, sample_num)
+        return (None, None, None, None, None, *([None] * nsets), *dfeats)
+
+
+def roi_extract(feats, roi_sets, strides, finest_scale=56, pooled=7, sample_num=0):
+    return RoIExtractFunction.apply(tuple(strides), finest_scale, pooled, sample_num, len(roi_sets), *roi_sets, *feats)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# AR-RFF head raw ops + autograd
+# ---------------------------------------------------------------------------------------------------------
+
+def conv3x3_fwd_op(x_view, roi_stride, R, C, w, b, relu, ws):
+    y = torch.empty(R, C, 7, 7, device=w.device)
+    check(hip.lib().arfe_conv3x3_fwd(R, C, x_view, roi_stride, ptr(w), ptr(b), int(relu), ptr(y), C * 49, ptr(ws),
+                                     stream()), "arfe_conv3x3_fwd")
+    return y
+
+
+def conv3x3_bwd_op(x_view, x_roi_stride, R, C, w, dy, relu_out, dx_view, dx_roi_stride, ws):
+    dw = torch.empty_like(w)
+    db = torch.empty(C, device=w.device)
+    check(hip.lib().arfe_conv3x3_bwd(R, C, x_view, x_roi_stride, ptr(w), ptr(dy), ptr(relu_out), C * 49, dx_view,
+                                     dx_roi_stride, ptr(dw), ptr(db), ptr(ws), stream()), "arfe_conv3x3_bwd")
+    return dw, db
+
+
+def linear_fwd_op(x, w, b, relu):
+    R, out_f, in_f = x.shape[0], w.shape[0], w.shape[1]
+    y = torch.empty(R, out_f, device=x.device)
+    check(hip.lib().arfe_linear_fwd(R, in_f, out_f, ptr(x), ptr(w), ptr(b), int(relu), ptr(y), stream()),
+          "arfe_linear_fwd")
+    return y
+
+
+def linear_bwd_op(x, w, dy, relu_out, dx=None, accumulate_dx=False, need_dx=True):
+    R, out_f, in_f = x.shape[0], w.shape[0], w.shape[1]
+    if need_dx and dx is None:
+        dx = torch.empty(R, in_f, device=x.device)
+    dw = torch.empty_like(w)
+    db = torch.empty(out_f, device=x.device)
+    check(hip.lib().arfe_linear_bwd(R, in_f, out_f, ptr(x), ptr(w), ptr(dy), ptr(relu_out), ptr(dx) if need_dx else 0,
+                                    int(accumulate_dx), ptr(dw), ptr(db), stream()), "arfe_linear_bwd")
+    return dx, dw, db
+
+
+class RFFHeadFunction(torch.autograd.Function):
+    """MultiBBoxHead.forward (num_shared_fcs=2): x [R,3C,7,7] -> (cls_score, bbox_pred).
+    args: x, w_wh, b_wh, w_hh, b_hh, w_f, b_f, w_fc1, b_fc1, w_fc2, b_fc2, w_cls, b_cls, w_reg, b_reg"""
+
+    @staticmethod
+    def forward(ctx, x, w_wh, b_wh, w_hh, b_hh, w_f, b_f, w1, b1, w2, b2, wc, bc, wr, br):
+        x = x.contiguous()
+        params = [p.contiguous() for p in (w_wh, b_wh, w_hh, b_hh, w_f, b_f, w1, b1, w2, b2, wc, bc, wr, br)]
+        w_wh, b_wh, w_hh, b_hh, w_f, b_f, w1, b1, w2, b2, wc, bc, wr, br = params
+        hip.require_f32_cuda(x, *params)
+        R, C3 = x.shape[0], x.shape[1]
+        C = C3 // 3
+        assert C3 == 3 * C and x.shape[2:] == (7, 7), "AR-RFF head expects [R, 3C, 7, 7]"
+        ws = _ws(hip.lib().arfe_conv3x3_workspace_bytes(C), x.device)
+        rs = C3 * 49
+        base = x.data_ptr()
+        lw = conv3x3_fwd_op(base + 4 * C * 49, rs, R, C, w_wh, b_wh, True, ws)
+        lh = conv3x3_fwd_op(base + 4 * 2 * C * 49, rs, R, C, w_hh, b_hh, True, ws)
+        z = torch.empty(R, C, 7, 7, device=x.device)
+        check(hip.lib().arfe_rff_fuse_fwd(R, C, base, rs, ptr(lw), ptr(lh), ptr(z), stream()), "arfe_rff_fuse_fwd")
+        z2 = conv3x3_fwd_op(z.data_ptr(), C * 49, R, C, w_f, b_f, True, ws)
+        f1 = linear_fwd_op(z2.view(R, -1), w1, b1, True)
+        f2 = linear_fwd_op(f1, w2, b2, True)
+        cls = linear_fwd_op(f2, wc, bc, False)
+        reg = linear_fwd_op(f2, wr, br, False)
+        ctx.save_for_backward(x, w_wh, w_hh, w_f, w1, w2, wc, wr, lw, lh, z, z2, f1, f2)
+        return cls, reg
+
+    @staticmethod
+    def backward(ctx, dcls, dreg):
+        x, w_wh, w_hh, w_f, w1, w2, wc, wr, lw, lh, z, z2, f1, f2 = ctx.saved_tensors
+        R, C3 = x.shape[0], x.shape[1]
+        C = C3 // 3
+        dev = x.device
+        rs = C3 * 49
+        dcls = dcls.contiguous() if dcls is not None else torch.zeros(R, wc.shape[0], device=dev)
+        dreg = dreg.contiguous() if dreg is not None else torch.zeros(R, wr.shape[0], device=dev)
+        ws = _ws(hip.lib().arfe_conv3x3_workspace_bytes(C), dev)
+        df2, dwc, dbc = linear_bwd_op(f2, wc, dcls, None)
+        _, dwr, dbr = linear_bwd_op(f2, wr, dreg, None, dx=df2, accumulate_dx=True)
+        df1, dw2, db2 = linear_bwd_op(f1, w2, df2, f2)
+        dz2, dw1, db1 = linear_bwd_op(z2.view(R, -1), w1, df1, f1)
+        dz = torch.empty(R, C, 7, 7, device=dev)
+        dwf, dbf = conv3x3_bwd_op(z.data_ptr(), C * 49, R, C, w_f, dz2, z2, dz.data_ptr(), C * 49, ws)
+        dx = torch.empty_like(x)
+        dl = torch.empty(R, C, 7, 7, device=dev)
+        check(hip.lib().arfe_rff_fuse_bwd(R, C, x.data_ptr(), rs, ptr(lw), ptr(lh), ptr(dz), dx.data_ptr(), rs, ptr(dl),
+                                          stream()), "arfe_rff_fuse_bwd")
+        dwwh, dbwh = conv3x3_bwd_op(x.data_ptr() + 4 * C * 49, rs, R, C, w_wh, dl, lw, dx.data_ptr() + 4 * C * 49, rs, ws)
+        dwhh, dbhh = conv3x3_bwd_op(x.data_ptr() + 8 * C * 49, rs, R, C, w_hh, dl, lh, dx.data_ptr() + 8 * C * 49, rs, ws)
+        return dx, dwwh, dbwh, dwhh, dbhh, dwf, dbf, dw1, db1, dw2, db2, dwc, dbc, dwr, dbr
+
+
+def rff_head(x, w_wh, b_wh, w_hh, b_hh, w_f, b_f, w1, b1, w2, b2, wc, bc, wr, br):
+    return RFFHeadFunction.apply(x, w_wh, b_wh, w_hh, b_hh, w_f, b_f, w1, b1, w2, b2, wc, bc, wr, br)

@@ -1,0 +1,180 @@
+/* libarfe_hip — C ABI of the MI355X-native (gfx950) AR-FPN / AR-RFF forward+backward hot path.
+ *
+ * The reference (Fanzhongjie/ARFE, a mmdetection 2.0 fork) has NO native boundary on this path: it is
+ * nn.Modules calling ATen ops.  This header is therefore the NEW boundary one level below
+ * the reference's Python plugin surface; every entry point names the reference code it replaces
+ * (paths relative to the reference root).  The host-side mirror of the plugin surface (same class names,
+ * ctor arguments, state_dict keys) lives in arfe_amd/ and calls these functions through ctypes.
+ *
+ * Conventions
+ *   - every function returns 0 (ARFE_OK) or a negative ARFE_ERR_* code; arfe_last_error() gives a
+ *     thread-local message.  No exception crosses the ABI.
+ *   - all pointers are raw DEVICE addresses of contiguous fp32 NCHW tensors (int32/int64 where stated).
+ *     The CALLER allocates every input, output and workspace buffer; the library holds no global mutable
+ *     state, is re-entrant, enqueues only on `stream` (a hipStream_t) and never synchronises the device.
+ *   - the device is selected by the caller (hipSetDevice / torch device guard).
+ *   - gradients are WRITTEN (not accumulated) unless stated.
+ */
+#ifndef ARFE_HIP_H
+#define ARFE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ARFE_ABI_VERSION 1
+#define ARFE_MAX_LEVELS 8
+
+#define ARFE_OK 0
+#define ARFE_ERR_ARG (-1)     /* bad shape / null pointer / unsupported size */
+#define ARFE_ERR_LAUNCH (-2)  /* hip launch error */
+
+/* Pyramid geometry shared by the AR-FPN entry points: level i is [batch, channels, height[i], width[i]]. */
+typedef struct arfe_pyramid {
+    int32_t num_levels;    /* <= ARFE_MAX_LEVELS */
+    int32_t refine_level;  /* WFPNDualSpatial(refine_level=2) */
+    int32_t batch;
+    int32_t channels;
+    int32_t height[ARFE_MAX_LEVELS];
+    int32_t width[ARFE_MAX_LEVELS];
+} arfe_pyramid_t;
+
+const char* arfe_last_error(void);
+int32_t arfe_abi_version(void);
+
+/* ======================================================================================================
+ * AR-FPN  (mmdet/models/necks/wfpn_dual_spatial.py: WFPNDualSpatial.forward :99-137)
+ * ==================================================================================================== */
+
+/* gather (:102-113): m = (((((0+G0)+G1)+G2)+G3)+G4)/num_levels, G_i = adaptive_max_pool2d (i < refine) or
+ * nearest (i >= refine) of x[i] to the refine level's size.  argmax (optional, may be NULL):
+ * [refine_level][B,C,hr,wr] int32 flat (y*w+x) index of each window's max, first max in row-major order
+ * (F.adaptive_max_pool2d tie-break), consumed by arfe_fpn_input_bwd. */
+int32_t arfe_fpn_gather_fwd(const arfe_pyramid_t* pyr, const float* const* x, float* m, int32_t* argmax,
+                            void* stream);
+
+/* gate maps (:119-121 + mmcv ConvModule's ReLU): a_i = tanh(relu(conv3x3(x_i; w1_i) + b1_i)),
+ * b_i likewise with (w2_i, b2_i); w*_i is [1,C,3,3], b*_i is [1]; a_i, b_i are [B,1,h_i,w_i].
+ * workspace: arfe_fpn_gatemap_workspace_bytes(pyr) bytes (per-channel-group partial sums). */
+int64_t arfe_fpn_gatemap_workspace_bytes(const arfe_pyramid_t* pyr);
+int32_t arfe_fpn_gatemap_fwd(const arfe_pyramid_t* pyr, const float* const* x, const float* const* w1,
+                             const float* const* b1, const float* const* w2, const float* const* b2,
+                             float* const* a, float* const* b, void* workspace, void* stream);
+
+/* scatter + gate + residual (:125,135): out_i = x_i + nearest(bsf -> h_i x w_i) * (a_i + b_i). */
+int32_t arfe_fpn_scatter_fwd(const arfe_pyramid_t* pyr, const float* const* x, const float* bsf,
+                             const float* const* a, const float* const* b, float* const* out, void* stream);
+
+/* backward of the scatter stage (autograd of :125,135), given g_i = dL/dout_i:
+ *   dm_i  = sum_c g_i[c] * U_i(bsf)[c]            da_i = dm_i (1 - a_i^2) [a_i > 0]   (same for b)
+ *   dbsf  = sum_i nearest^T( g_i * (a_i + b_i) )
+ * outputs: dpre_a[i], dpre_b[i] ([B,1,h_i,w_i], gradient w.r.t. the conv pre-activation) and dbsf [B,C,hr,wr]. */
+int32_t arfe_fpn_scatter_bwd(const arfe_pyramid_t* pyr, const float* const* gout, const float* bsf,
+                             const float* const* a, const float* const* b, float* const* dpre_a,
+                             float* const* dpre_b, float* dbsf, void* stream);
+
+/* dx_i = g_i + conv3x3^T(dpre_a_i; w1_i) + conv3x3^T(dpre_b_i; w2_i) + gather^T(dm / num_levels)
+ * (dm = gradient w.r.t. the gathered mean m, [B,C,hr,wr]; argmax from arfe_fpn_gather_fwd). */
+int32_t arfe_fpn_input_bwd(const arfe_pyramid_t* pyr, const float* const* gout, const float* const* dpre_a,
+                           const float* const* dpre_b, const float* const* w1, const float* const* w2,
+                           const float* dm, const int32_t* argmax, float* const* dx, void* stream);
+
+/* gate-conv parameter gradients: dw1_i[c,tap] = sum x_i[c, y+dy, x+dx] dpre_a_i[y,x], db1_i = sum dpre_a_i
+ * (same for 2).  dw*_i [1,C,3,3], db*_i [1]. */
+int32_t arfe_fpn_gate_wgrad(const arfe_pyramid_t* pyr, const float* const* x, const float* const* dpre_a,
+                            const float* const* dpre_b, float* const* dw1, float* const* db1,
+                            float* const* dw2, float* const* db2, void* stream);
+
+/* ======================================================================================================
+ * NonLocal2D refine  (mmdet/ops/non_local.py :63-70, :78-105; reduction=1, use_scale=False,
+ * mode='embedded_gaussian').  L = h*w of the refine level.
+ *   tpg  = [Wt;Wp;Wg] m + [bt;bp;bg]        [B,3C,L]   (theta | phi | g)
+ *   P    = softmax_rows(theta^T phi)        [B,L,L]    (materialised: 4 B * L^2 per image; on exact-fp32
+ *                                                        MFMA the block is compute-bound, recompute costs more)
+ *   y    = g P^T  (y[c,i] = sum_j P[i,j] g[c,j])        [B,C,L]
+ *   bsf  = m + Wo y + bo                                [B,C,L]
+ * Saved for backward (caller-allocated): tpg, P, y.
+ * ==================================================================================================== */
+int64_t arfe_nonlocal_workspace_bytes(int32_t B, int32_t C, int32_t L);   /* fwd and bwd scratch */
+
+int32_t arfe_nonlocal_fwd(int32_t B, int32_t C, int32_t L, const float* m, const float* w_theta,
+                          const float* b_theta, const float* w_phi, const float* b_phi, const float* w_g,
+                          const float* b_g, const float* w_out, const float* b_out, float* tpg, float* P,
+                          float* y, float* bsf, void* workspace, void* stream);
+
+/* dm = dbsf + [Wt;Wp;Wg]^T d(tpg); all eight parameter gradients are written. `dP` is an [B,L,L] scratch. */
+int32_t arfe_nonlocal_bwd(int32_t B, int32_t C, int32_t L, const float* dbsf, const float* m,
+                          const float* w_theta, const float* w_phi, const float* w_g, const float* w_out,
+                          const float* tpg, const float* P, const float* y, float* dP, float* dm,
+                          float* dw_theta, float* db_theta, float* dw_phi, float* db_phi, float* dw_g,
+                          float* db_g, float* dw_out, float* db_out, void* workspace, void* stream);
+
+/* ======================================================================================================
+ * AR-RFF
+ * ==================================================================================================== */
+
+/* get_adaptive_scale_rois(rois, facs=1) (mmdet/models/utils/additional.py:38-71): rois [R,5] = (b,x1,y1,x2,y2)
+ * -> h_rois, w_rois [R,5]; same fp32 op order as the reference (bit-exact). */
+int32_t arfe_rff_make_rois(int32_t R, const float* rois, float* h_rois, float* w_rois, void* stream);
+
+/* SingleRoIExtractor.map_roi_levels (roi_extractors/single_level.py:53-93):
+ * clamp(floor(log2(sqrt((x2-x1)(y2-y1)) / finest_scale + 1e-6)), 0, num_levels-1) as int64, bit-exact with the
+ * reference's fp32 torch-CPU result (the device compares against the fp32 values at which torch's
+ * floor(log2(.)) steps; no transcendental is evaluated). num_levels <= 5. */
+int32_t arfe_map_roi_levels(int32_t R, const float* rois, int32_t num_levels, float finest_scale,
+                            int64_t* levels, void* stream);
+
+/* RoIAlign v2 (aligned=True, sample_num=0 -> adaptive grid; mmdet/ops/roi_align/src/cpu/roi_align_v2.cpp
+ * :107-191 fwd, :247-332 bwd; CUDA kernels src/cuda/roi_align_kernel_v2.cu:63-129,180-) fused with the
+ * per-level dispatch of SingleRoIExtractor.forward (single_level.py:109-152): RoI k samples level levels[k]
+ * with spatial scale 1/strides[level].  out is written at out + k*out_roi_stride + c*P*P (so three calls fill
+ * the [R, 3C, 7, 7] concat of standard_roi_head.py:155 in place).  Returns ARFE_ERR_ARG for P != 7. */
+int32_t arfe_roialign_fwd(const arfe_pyramid_t* pyr, const float* const* feats, const int32_t* strides,
+                          int32_t R, const float* rois, const int64_t* levels, int32_t pooled,
+                          int32_t sample_num, float* out, int64_t out_roi_stride, void* stream);
+
+/* dfeats[i] += RoIAlign^T(gout) (atomic accumulation: the CALLER zeroes dfeats before the first call). */
+int32_t arfe_roialign_bwd(const arfe_pyramid_t* pyr, float* const* dfeats, const int32_t* strides, int32_t R,
+                          const float* rois, const int64_t* levels, int32_t pooled, int32_t sample_num,
+                          const float* gout, int64_t gout_roi_stride, void* stream);
+
+/* 3x3 conv, padding 1, on RoI features [R, C, 7, 7] (MultiBBoxHead wh_conv/hh_conv/final_conv,
+ * bbox_heads/multirois_bbox_head.py:50-78,172-173,183): y = act(conv(x; w) + b).  x/y are addressed as
+ * base + r*roi_stride + c*49 + p so a channel slice of the [R,3C,7,7] concat is passed without a copy.
+ * workspace: arfe_conv3x3_workspace_bytes(C). */
+int64_t arfe_conv3x3_workspace_bytes(int32_t C);
+int32_t arfe_conv3x3_fwd(int32_t R, int32_t C, const float* x, int64_t x_roi_stride, const float* w,
+                         const float* b, int32_t relu, float* y, int64_t y_roi_stride, void* workspace,
+                         void* stream);
+/* dy_eff = relu_out ? dy * [relu_out > 0] : dy ; dx = conv^T(dy_eff), dw = x (*) dy_eff, db = sum dy_eff.
+ * relu_out (the forward output, may be NULL) shares dy's addressing. dx may be NULL. */
+int32_t arfe_conv3x3_bwd(int32_t R, int32_t C, const float* x, int64_t x_roi_stride, const float* w,
+                         const float* dy, const float* relu_out, int64_t dy_roi_stride, float* dx,
+                         int64_t dx_roi_stride, float* dw, float* db, void* workspace, void* stream);
+
+/* fusion (multirois_bbox_head.py:175-182): z = ori + ori * (lw + lh); ori is a slice (roi stride given),
+ * lw, lh, z are dense [R,C,7,7]. */
+int32_t arfe_rff_fuse_fwd(int32_t R, int32_t C, const float* ori, int64_t ori_roi_stride, const float* lw,
+                          const float* lh, float* z, void* stream);
+/* d_ori = dz (1 + lw + lh) ; dlw = dz * ori ; dlh = dz * ori  (the ReLU masks of lw/lh are applied by
+ * arfe_conv3x3_bwd through relu_out).  d_ori is written with d_ori_roi_stride; dlw == dlh is written once. */
+int32_t arfe_rff_fuse_bwd(int32_t R, int32_t C, const float* ori, int64_t ori_roi_stride, const float* lw,
+                          const float* lh, const float* dz, float* d_ori, int64_t d_ori_roi_stride,
+                          float* dl, void* stream);
+
+/* nn.Linear (shared_fcs / fc_cls / fc_reg, multirois_bbox_head.py:203-235): y = act(x W^T + b),
+ * x [R,in], W [out,in], y [R,out]. */
+int32_t arfe_linear_fwd(int32_t R, int32_t in_f, int32_t out_f, const float* x, const float* w, const float* b,
+                        int32_t relu, float* y, void* stream);
+/* dy_eff = relu_out ? dy*[relu_out>0] : dy; dx = dy_eff W (written, or accumulated when accumulate_dx != 0;
+ * dx may be NULL), dw = dy_eff^T x, db = colsum(dy_eff). */
+int32_t arfe_linear_bwd(int32_t R, int32_t in_f, int32_t out_f, const float* x, const float* w,
+                        const float* dy, const float* relu_out, float* dx, int32_t accumulate_dx, float* dw,
+                        float* db, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ARFE_HIP_H */

@@ -1,0 +1,296 @@
+"""GPU parity: every HIP stage (called through the C ABI, arfe_amd.functional) against the CPU oracle on the
+same seeded inputs, and against the golden vectors generated from the reference (tests/golden).
+
+Tolerance: north_star asks for 1e-3 relative in fp32 (max|a-b|/max|b|); the kernels are exact-fp32 so the
+asserts are set tighter (TOL) to catch indexing bugs, bit-exact for integer/index results."""
+import pytest
+import torch
+
+from conftest import load_golden, relerr
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-5          # exact fp32 arithmetic, different summation order
+TOL_GRAD = 1e-4     # gradients (atomics, long reductions)
+NORTH_STAR_TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def Fn():
+    from arfe_amd import functional
+    from arfe_amd import hip
+    hip.lib()       # fail loudly if the HIP library is missing
+    return functional
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import arfe_oracle
+    return arfe_oracle
+
+
+def cu(ts, dev):
+    return [t.to(dev).contiguous() for t in ts]
+
+
+PYRAMIDS = {
+    'tiny': ((16, 24), (8, 12), (4, 6), (2, 3), (1, 2)),
+    'ragged': ((40, 67), (20, 34), (10, 17), (5, 9), (3, 5)),
+    'mid': ((64, 96), (32, 48), (16, 24), (8, 12), (4, 6)),
+    'odd': ((50, 83), (25, 42), (13, 21), (7, 11), (4, 6)),
+}
+
+
+@pytest.mark.parametrize('shape', list(PYRAMIDS))
+@pytest.mark.parametrize('r', [0, 2, 3, 4])
+def test_gather_matches_oracle(Fn, O, dev, shape, r):
+    g = torch.Generator().manual_seed(1)
+    xs = [torch.randn(2, 12, h, w, generator=g) for h, w in PYRAMIDS[shape]]
+    m, argmax = Fn.fpn_gather_op(cu(xs, dev), r)
+    ref = O.fpn_gather(xs, r, explicit=True)
+    assert torch.equal(m.cpu(), ref), "gather is max/copy/add/div: must be bit-exact"
+    hr, wr = xs[r].shape[2:]
+    for i in range(r):
+        _, idx = torch.nn.functional.adaptive_max_pool2d(xs[i], (hr, wr), return_indices=True)
+        assert torch.equal(argmax[i].cpu().long(), idx), f"argmax level {i}"
+
+
+@pytest.mark.parametrize('shape', list(PYRAMIDS))
+def test_gatemap_matches_oracle(Fn, O, dev, shape):
+    g = torch.Generator().manual_seed(2)
+    C = 20
+    xs = [torch.randn(2, C, h, w, generator=g) for h, w in PYRAMIDS[shape]]
+    w1 = [torch.randn(1, C, 3, 3, generator=g) * 0.1 for _ in xs]
+    w2 = [torch.randn(1, C, 3, 3, generator=g) * 0.1 for _ in xs]
+    b1 = [torch.randn(1, generator=g) * 0.1 for _ in xs]
+    b2 = [torch.randn(1, generator=g) * 0.1 for _ in xs]
+    a, b = Fn.fpn_gatemap_op(cu(xs, dev), cu(w1, dev), cu(b1, dev), cu(w2, dev), cu(b2, dev))
+    for i, x in enumerate(xs):
+        ra, rb = O.gate_maps(x, w1[i], b1[i], w2[i], b2[i])
+        assert relerr(a[i], ra) <= TOL and relerr(b[i], rb) <= TOL, i
+        assert (a[i].cpu() > 0).eq(ra > 0).float().mean() > 0.999
+
+
+@pytest.mark.parametrize('shape', list(PYRAMIDS))
+@pytest.mark.parametrize('r', [2, 3])
+def test_scatter_matches_oracle(Fn, O, dev, shape, r):
+    g = torch.Generator().manual_seed(3)
+    C = 9
+    xs = [torch.randn(2, C, h, w, generator=g) for h, w in PYRAMIDS[shape]]
+    bsf = torch.randn(2, C, *PYRAMIDS[shape][r], generator=g)
+    a = [torch.rand(2, 1, h, w, generator=g) for h, w in PYRAMIDS[shape]]
+    b = [torch.rand(2, 1, h, w, generator=g) for h, w in PYRAMIDS[shape]]
+    outs = Fn.fpn_scatter_op(cu(xs, dev), bsf.to(dev), cu(a, dev), cu(b, dev), r)
+    for i in range(5):
+        ref = O.fpn_scatter(xs[i], bsf, a[i], b[i], explicit=True)
+        assert relerr(outs[i], ref) <= 1e-6, i
+
+
+@pytest.mark.parametrize('B,C,h,w', [(1, 8, 4, 6), (2, 16, 10, 17), (1, 256, 13, 21), (2, 64, 25, 42)])
+def test_nonlocal_fwd_bwd_matches_oracle(Fn, O, dev, B, C, h, w):
+    g = torch.Generator().manual_seed(4)
+    p = {k: v for k, v in O.arfpn_params(C, 5, seed=5).items() if k.startswith('refine')}
+    for k in list(p):
+        if k.endswith('bias'):
+            p[k] = torch.randn(p[k].shape, generator=g) * 0.1
+        p[k] = p[k].requires_grad_(True)
+    m = torch.randn(B, C, h, w, generator=g, requires_grad=True)
+    cot = torch.randn(B, C, h, w, generator=g)
+    ref = O.nonlocal_refine(m, p)
+    (ref * cot).sum().backward()
+    names = ['theta', 'phi', 'g', 'conv_out']
+    W = [p[f'refine.{n}.conv.weight'].detach().view(C, C).to(dev) for n in names]
+    Bv = [p[f'refine.{n}.conv.bias'].detach().to(dev) for n in names]
+    md = m.detach().to(dev)
+    bsf, saved = Fn.nonlocal_fwd_op(md, W[0], Bv[0], W[1], Bv[1], W[2], Bv[2], W[3], Bv[3])
+    assert relerr(bsf, ref) <= TOL
+    dm, grads = Fn.nonlocal_bwd_op(cot.to(dev), md, W[0], W[1], W[2], W[3], saved)
+    assert relerr(dm, m.grad) <= TOL_GRAD
+    dwt, dbt, dwp, dbp, dwg, dbg, dwo, dbo = grads
+    for got, n in ((dwt, 'theta'), (dwp, 'phi'), (dwg, 'g'), (dwo, 'conv_out')):
+        assert relerr(got.view(C, C, 1, 1), p[f'refine.{n}.conv.weight'].grad) <= TOL_GRAD, n
+    for got, n in ((dbt, 'theta'), (dbg, 'g'), (dbo, 'conv_out')):
+        assert relerr(got, p[f'refine.{n}.conv.bias'].grad) <= TOL_GRAD, n
+    # d/d(b_phi) is identically zero (row-constant logit shift): only rounding noise on both sides
+    assert dbp.abs().max().item() <= 1e-3 * max(dbt.abs().max().item(), 1e-12)
+
+
+def _run_arfpn(Fn, dev, d, r):
+    xs = [d[f'x{i}'].to(dev).requires_grad_(True) for i in range(5)]
+    p = {k[2:]: v.to(dev).requires_grad_(True) for k, v in d.items() if k.startswith('p.')}
+    C = xs[0].shape[1]
+    w1 = [p[f'reduce_convs.{i}.conv.weight'] for i in range(5)]
+    b1 = [p[f'reduce_convs.{i}.conv.bias'] for i in range(5)]
+    w2 = [p[f'reduce_convs2.{i}.conv.weight'] for i in range(5)]
+    b2 = [p[f'reduce_convs2.{i}.conv.bias'] for i in range(5)]
+    nl = []
+    for n in ('theta', 'phi', 'g', 'conv_out'):
+        nl += [p[f'refine.{n}.conv.weight'].view(C, C), p[f'refine.{n}.conv.bias']]
+    outs = Fn.arfpn(xs, w1, b1, w2, b2, *nl, refine_level=r)
+    return xs, p, outs
+
+
+@pytest.mark.parametrize('name', ['arfpn_tiny_r2.npz', 'arfpn_tiny_r3.npz', 'arfpn_ragged_r2.npz',
+                                  'arfpn_ragged_r3.npz', 'arfpn_peaky_r2.npz'])
+def test_arfpn_golden_fwd_bwd(Fn, dev, name):
+    d = load_golden(name)
+    r = int(d['refine_level'])
+    xs, p, outs = _run_arfpn(Fn, dev, d, r)
+    for i in range(5):
+        assert relerr(outs[i], d[f'out{i}']) <= TOL, (name, i)
+    sum((o * d[f'cot{i}'].to(dev)).sum() for i, o in enumerate(outs)).backward()
+    for i in range(5):
+        assert relerr(xs[i].grad, d[f'dx{i}']) <= TOL_GRAD, (name, 'dx', i)
+    ref_scale = d['dp.refine.theta.conv.bias'].abs().max().item()
+    for k, v in p.items():
+        if k == 'refine.phi.conv.bias':
+            assert v.grad.abs().max().item() <= 1e-3 * ref_scale
+            continue
+        assert relerr(v.grad, d['dp.' + k]) <= TOL_GRAD, (name, k)
+
+
+def test_arfpn_full_size_checksums(Fn, O, dev):
+    """BASELINE size (B=1, 256 ch, 1333x800 pyramid) against checksums of the reference's own run."""
+    import numpy as np
+    import os
+    from conftest import GOLDEN
+    z = np.load(os.path.join(GOLDEN, 'arfpn_full_r2_checksum.npz'))
+    p = {k: v.to(dev).requires_grad_(True) for k, v in O.arfpn_params(256, 5, seed=11).items()}
+    xs = [x.to(dev).requires_grad_(True) for x in O.synth_pyramid(1, 256, seed=1234)]
+    cots = [c.to(dev) for c in O.synth_pyramid(1, 256, seed=4321)]
+    w1 = [p[f'reduce_convs.{i}.conv.weight'] for i in range(5)]
+    b1 = [p[f'reduce_convs.{i}.conv.bias'] for i in range(5)]
+    w2 = [p[f'reduce_convs2.{i}.conv.weight'] for i in range(5)]
+    b2 = [p[f'reduce_convs2.{i}.conv.bias'] for i in range(5)]
+    nl = []
+    for n in ('theta', 'phi', 'g', 'conv_out'):
+        nl += [p[f'refine.{n}.conv.weight'].view(256, 256), p[f'refine.{n}.conv.bias']]
+    outs = Fn.arfpn(xs, w1, b1, w2, b2, *nl, refine_level=2)
+    sum((o * c).sum() for o, c in zip(outs, cots)).backward()
+
+    def check(t, key, tol):
+        t = t.detach().double().flatten().cpu()
+        s = z[key + '.samples']
+        got = t[torch.from_numpy(z[key + '.idx'])].numpy()
+        assert np.abs(got - s).max() <= tol * max(np.abs(s).max(), 1e-30), key
+        assert abs(t.abs().sum().item() - z[key + '.abssum']) <= tol * z[key + '.abssum'], key
+
+    for i in range(5):
+        check(outs[i], f'out{i}', NORTH_STAR_TOL)
+        check(xs[i].grad, f'dx{i}', NORTH_STAR_TOL)
+    for k, v in p.items():
+        if k != 'refine.phi.conv.bias':
+            check(v.grad, 'dp.' + k, NORTH_STAR_TOL)
+
+
+def test_make_rois_bit_exact(Fn, dev):
+    d = load_golden('rois_make.npz')
+    h, w = Fn.make_rois_op(d['rois'].to(dev))
+    assert torch.equal(h.cpu(), d['h_rois']) and torch.equal(w.cpu(), d['w_rois'])
+
+
+def test_map_roi_levels_bit_exact(Fn, O, dev):
+    d = load_golden('roi_levels.npz')
+    for nl, key in ((5, 'levels5'), (4, 'levels4')):
+        lv = Fn.map_roi_levels_op(d['rois'].to(dev), nl)
+        assert lv.dtype == torch.int64 and torch.equal(lv.cpu(), d[key])
+    # against the oracle (torch-CPU log2 on THIS host) on the bench's synthetic RoIs and their enlarged sets
+    rois = O.synth_rois(2, 512)
+    h, w = O.make_rois(rois)
+    for r in (rois, h, w):
+        assert torch.equal(Fn.map_roi_levels_op(r.to(dev), 5).cpu(), O.map_roi_levels(r, 5))
+    assert Fn.map_roi_levels_op(torch.zeros(0, 5, device=dev), 5).numel() == 0
+
+
+def test_roialign_golden(Fn, dev):
+    d = load_golden('roialign.npz')
+    feats = [d[f'feat{i}'].to(dev).requires_grad_(True) for i in range(5)]
+    rois = d['rois'].to(dev)
+    h_r, w_r = Fn.make_rois_op(rois)
+    cat = Fn.roi_extract(feats, [rois, w_r, h_r], (4, 8, 16, 32, 64))
+    assert relerr(cat, d['cat']) <= TOL
+    (cat * d['cot'].to(dev)).sum().backward()
+    for i in range(5):
+        g = feats[i].grad if feats[i].grad is not None else torch.zeros_like(feats[i])
+        assert relerr(g, d[f'dfeat{i}']) <= TOL_GRAD, i
+    # fixed sample_num through the single-level layer
+    from arfe_amd import RoIAlign
+    layer = RoIAlign(7, 1.0 / 8, sample_num=2)
+    assert relerr(layer(d['feat1'].to(dev), rois), d['single_lvl1_sn2']) <= TOL
+
+
+@pytest.mark.parametrize('name', ['rff_head_r8.npz', 'rff_head_r40.npz'])
+def test_rff_head_golden(Fn, dev, name):
+    d = load_golden(name)
+    x = d['x'].to(dev).requires_grad_(True)
+    p = {k[2:]: v.to(dev).requires_grad_(True) for k, v in d.items() if k.startswith('p.')}
+    cls, reg = Fn.rff_head(x, p['wh_conv.conv.weight'], p['wh_conv.conv.bias'], p['hh_conv.conv.weight'],
+                           p['hh_conv.conv.bias'], p['final_conv.conv.weight'], p['final_conv.conv.bias'],
+                           p['shared_fcs.0.weight'], p['shared_fcs.0.bias'], p['shared_fcs.1.weight'],
+                           p['shared_fcs.1.bias'], p['fc_cls.weight'], p['fc_cls.bias'], p['fc_reg.weight'],
+                           p['fc_reg.bias'])
+    assert relerr(cls, d['cls']) <= TOL and relerr(reg, d['reg']) <= TOL
+    ((cls * d['cot_cls'].to(dev)).sum() + (reg * d['cot_reg'].to(dev)).sum()).backward()
+    assert relerr(x.grad, d['dx']) <= TOL_GRAD
+    for k, v in p.items():
+        assert relerr(v.grad, d['dp.' + k]) <= TOL_GRAD, k
+
+
+def test_end_to_end_golden_through_plugin_surface(dev):
+    """Registry-built modules with the reference's state_dict keys: neck -> 3-RoI extractor -> head."""
+    import arfe_amd
+    d = load_golden('e2e_small.npz')
+    C = d['x0'].shape[1]
+    neck = arfe_amd.build_neck(dict(type='WFPNDualSpatial', in_channels=C, num_levels=5)).to(dev)
+    roi_head = arfe_amd.build_head(dict(
+        type='StandardRoIHead',
+        bbox_roi_extractor=dict(type='SingleRoIExtractor', roi_layer=dict(type='RoIAlign', out_size=7, sample_num=0),
+                                out_channels=C, featmap_strides=[4, 8, 16, 32, 64]),
+        bbox_head=dict(type='MultiRoIsBBoxHead', in_channels=C, conv_out_channels=C, fc_out_channels=24,
+                       roi_feat_size=7, num_classes=80))).to(dev)
+    neck.load_state_dict({k[5:]: v for k, v in d.items() if k.startswith('neck.')})
+    roi_head.bbox_head.load_state_dict({k[5:]: v for k, v in d.items() if k.startswith('head.')})
+    xs = [d[f'x{i}'].to(dev).requires_grad_(True) for i in range(5)]
+    feats = neck(xs)
+    for i in range(5):
+        assert relerr(feats[i], d[f'feat{i}']) <= TOL, i
+    res = roi_head._bbox_forward(feats, d['rois'].to(dev))
+    assert relerr(res['bbox_feats'], d['bbox_feats']) <= TOL
+    assert relerr(res['cls_score'], d['cls']) <= 5e-5 and relerr(res['bbox_pred'], d['reg']) <= 5e-5
+    ((res['cls_score'] * d['cot_cls'].to(dev)).sum() + (res['bbox_pred'] * d['cot_reg'].to(dev)).sum()).backward()
+    for i in range(5):
+        assert relerr(xs[i].grad, d[f'dx{i}']) <= TOL_GRAD, i
+    for k, v in neck.named_parameters():
+        if k == 'refine.phi.conv.bias':
+            continue
+        assert relerr(v.grad, d['dneck.' + k]) <= TOL_GRAD, k
+    for k, v in roi_head.bbox_head.named_parameters():
+        assert relerr(v.grad, d['dhead.' + k]) <= TOL_GRAD, k
+
+
+def test_full_size_properties(Fn, O, dev):
+    """BASELINE-size (B=2) properties that need no CPU reference run:
+    scatter with zero gates is the identity; the path is linear in the upstream cotangent; empty RoI sets."""
+    xs = [x.to(dev) for x in O.synth_pyramid(2, 256, seed=77)]
+    bsf = torch.randn(2, 256, 50, 84, device=dev)
+    zeros = [torch.zeros(2, 1, *x.shape[2:], device=dev) for x in xs]
+    outs = Fn.fpn_scatter_op(xs, bsf, zeros, zeros, 2)
+    assert all(torch.equal(o, x) for o, x in zip(outs, xs))
+    ones = [torch.full((2, 1, *x.shape[2:]), 0.5, device=dev) for x in xs]
+    outs = Fn.fpn_scatter_op(xs, bsf, ones, ones, 2)       # a + b == 1 -> out - x == nearest(bsf)
+    up = outs[0] - xs[0]
+    assert relerr(up[:, :, ::4, ::4], bsf) <= 1e-6
+    # backward linearity: dbsf(2g) == 2 dbsf(g)
+    g = [torch.randn_like(x) for x in xs]
+    _, _, d1 = Fn.fpn_scatter_bwd_op(g, bsf, ones, ones, 2)
+    _, _, d2 = Fn.fpn_scatter_bwd_op([2 * t for t in g], bsf, ones, ones, 2)
+    assert relerr(d2, 2 * d1) <= 1e-6
+    # empty RoI set
+    out = Fn.roi_extract(xs, [torch.zeros(0, 5, device=dev)], (4, 8, 16, 32, 64))
+    assert out.shape == (0, 256, 7, 7)
