@@ -357,71 +357,77 @@ extern "C" int32_t arfe_linear_bwd(int32_t R, int32_t in_f, int32_t out_f, const
 // =========================================================================================================
 // 3x3 conv on RoI tiles
 // =========================================================================================================
+extern "C" int64_t arfe_conv3x3_packed_bytes(int32_t C) {
+    // wp[tap][co][ci] followed by wd[tap][ci][co] (flipped/transposed for the data gradient)
+    return (int64_t)2 * 9 * C * C * sizeof(float);
+}
 extern "C" int64_t arfe_conv3x3_workspace_bytes(int32_t C) {
-    // wp + wd (permuted weights) + dwp (permuted weight gradient)
-    return (int64_t)3 * 9 * C * C * sizeof(float);
+    return (int64_t)9 * C * C * sizeof(float);   // permuted weight-gradient accumulator
 }
 
-extern "C" int32_t arfe_conv3x3_fwd(int32_t R, int32_t C, const float* x, int64_t x_roi_stride, const float* w,
-                                    const float* b, int32_t relu, float* y, int64_t y_roi_stride, void* workspace,
-                                    void* stream) {
-    ARFE_CHECK_ARG(R >= 0 && C > 0, ARFE_ERR_ARG, "conv3x3_fwd: bad shape");
-    if (R == 0) return ARFE_OK;
-    ARFE_CHECK_ARG(x && w && y && workspace, ARFE_ERR_ARG, "conv3x3_fwd: null pointer");
-    hipStream_t st = as_stream(stream);
-    float* wp = (float*)workspace;
+extern "C" int32_t arfe_conv3x3_pack_weights(int32_t C, const float* w, void* packed, void* stream) {
+    ARFE_CHECK_ARG(C > 0 && w && packed, ARFE_ERR_ARG, "conv3x3_pack_weights: bad arguments");
+    float* wp = (float*)packed;
     float* wd = wp + (size_t)9 * C * C;
     int total = 9 * C * C;
-    hipLaunchKernelGGL(conv_w_permute_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, w, wp, wd, C);
+    hipLaunchKernelGGL(conv_w_permute_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), w, wp, wd, C);
     ARFE_CHECK_LAUNCH();
+    return ARFE_OK;
+}
+
+extern "C" int32_t arfe_conv3x3_fwd(int32_t R, int32_t C, const float* x, int64_t x_roi_stride, const void* packed,
+                                    const float* b, int32_t relu, float* y, int64_t y_roi_stride, void* stream) {
+    ARFE_CHECK_ARG(R >= 0 && C > 0, ARFE_ERR_ARG, "conv3x3_fwd: bad shape");
+    if (R == 0) return ARFE_OK;
+    ARFE_CHECK_ARG(x && packed && y, ARFE_ERR_ARG, "conv3x3_fwd: null pointer");
+    const float* wp = (const float*)packed;
     LoadRowMajorK la{wp, 0, (int64_t)C * C, C, C, C};     // A(m=co,k=ci) for tap kb
     ConvGatherB lb{x, nullptr, x_roi_stride, 0, R * 49, C};
     EpiConv e{y, y_roi_stride, b, relu};
-    return launch_gemm(C, R * 49, C, 9, 1, 1, la, lb, e, st);
+    return launch_gemm(C, R * 49, C, 9, 1, 1, la, lb, e, as_stream(stream));
 }
 
-extern "C" int32_t arfe_conv3x3_bwd(int32_t R, int32_t C, const float* x, int64_t x_roi_stride, const float* w,
-                                    const float* dy, const float* relu_out, int64_t dy_roi_stride, float* dx,
-                                    int64_t dx_roi_stride, float* dw, float* db, void* workspace, void* stream) {
-    ARFE_CHECK_ARG(R >= 0 && C > 0, ARFE_ERR_ARG, "conv3x3_bwd: bad shape");
-    hipStream_t st = as_stream(stream);
-    if (dw && hipMemsetAsync(dw, 0, sizeof(float) * (size_t)9 * C * C, st) != hipSuccess) return ARFE_ERR_LAUNCH;
-    if (db && hipMemsetAsync(db, 0, sizeof(float) * (size_t)C, st) != hipSuccess) return ARFE_ERR_LAUNCH;
+extern "C" int32_t arfe_conv3x3_bwd_data(int32_t R, int32_t C, const void* packed, const float* dy,
+                                         const float* relu_out, int64_t dy_roi_stride, float* dx,
+                                         int64_t dx_roi_stride, void* stream) {
+    ARFE_CHECK_ARG(R >= 0 && C > 0, ARFE_ERR_ARG, "conv3x3_bwd_data: bad shape");
     if (R == 0) return ARFE_OK;
-    ARFE_CHECK_ARG(x && w && dy && workspace, ARFE_ERR_ARG, "conv3x3_bwd: null pointer");
-    float* wp = (float*)workspace;
-    float* wd = wp + (size_t)9 * C * C;
-    float* dwp = wd + (size_t)9 * C * C;
+    ARFE_CHECK_ARG(packed && dy && dx, ARFE_ERR_ARG, "conv3x3_bwd_data: null pointer");
+    const float* wd = (const float*)packed + (size_t)9 * C * C;
+    LoadRowMajorK la{wd, 0, (int64_t)C * C, C, C, C};      // A(m=ci,k=co) = w[co][ci][8-tap]
+    ConvGatherB lb{dy, relu_out, dy_roi_stride, dy_roi_stride, R * 49, C};
+    EpiConv e{dx, dx_roi_stride, nullptr, 0};
+    return launch_gemm(C, R * 49, C, 9, 1, 1, la, lb, e, as_stream(stream));
+}
+
+extern "C" int32_t arfe_conv3x3_bwd_weight(int32_t R, int32_t C, const float* x, int64_t x_roi_stride,
+                                           const float* dy, const float* relu_out, int64_t dy_roi_stride,
+                                           float* dw, float* db, void* workspace, void* stream) {
+    ARFE_CHECK_ARG(R >= 0 && C > 0 && dw && db, ARFE_ERR_ARG, "conv3x3_bwd_weight: bad arguments");
+    hipStream_t st = as_stream(stream);
+    if (hipMemsetAsync(db, 0, sizeof(float) * (size_t)C, st) != hipSuccess) return ARFE_ERR_LAUNCH;
+    if (R == 0) {
+        if (hipMemsetAsync(dw, 0, sizeof(float) * (size_t)9 * C * C, st) != hipSuccess) return ARFE_ERR_LAUNCH;
+        return ARFE_OK;
+    }
+    ARFE_CHECK_ARG(x && dy && workspace, ARFE_ERR_ARG, "conv3x3_bwd_weight: null pointer");
+    float* dwp = (float*)workspace;
     int total = 9 * C * C;
-    int32_t rc;
-    if (dx) {
-        hipLaunchKernelGGL(conv_w_permute_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, w, wp, wd, C);
-        ARFE_CHECK_LAUNCH();
-        LoadRowMajorK la{wd, 0, (int64_t)C * C, C, C, C};  // A(m=ci,k=co) = w[co][ci][8-tap]
-        ConvGatherB lb{dy, relu_out, dy_roi_stride, dy_roi_stride, R * 49, C};
-        EpiConv e{dx, dx_roi_stride, nullptr, 0};
-        rc = launch_gemm(C, R * 49, C, 9, 1, 1, la, lb, e, st);
-        if (rc) return rc;
-    }
-    if (dw) {
-        if (hipMemsetAsync(dwp, 0, sizeof(float) * (size_t)total, st) != hipSuccess) return ARFE_ERR_LAUNCH;
-        WgradA la{dy, relu_out, dy_roi_stride, C, R * 49};
-        WgradB lb{x, x_roi_stride, C, R * 49};
-        int ksteps = cdiv(R * 49, GEMM_BK);
-        int splitk = pick_splitk(C, C, 9, ksteps);
-        EpiPlain e = epi_plain(dwp, (int64_t)C * C, C);
-        e.atomic = 1;
-        rc = launch_gemm(C, C, R * 49, 1, 9, splitk, la, lb, e, st);
-        if (rc) return rc;
-        hipLaunchKernelGGL(conv_dw_unpermute_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, dwp, dw, C);
-        ARFE_CHECK_LAUNCH();
-    }
-    if (db) {
-        int chunk = 32;
-        dim3 grid(C, cdiv(R, chunk));
-        hipLaunchKernelGGL(reduce_mid_kernel, grid, dim3(64), 0, st, dy, relu_out, db, R, dy_roi_stride, 49, chunk);
-        ARFE_CHECK_LAUNCH();
-    }
+    if (hipMemsetAsync(dwp, 0, sizeof(float) * (size_t)total, st) != hipSuccess) return ARFE_ERR_LAUNCH;
+    WgradA la{dy, relu_out, dy_roi_stride, C, R * 49};
+    WgradB lb{x, x_roi_stride, C, R * 49};
+    int ksteps = cdiv(R * 49, GEMM_BK);
+    int splitk = pick_splitk(C, C, 9, ksteps);
+    EpiPlain e = epi_plain(dwp, (int64_t)C * C, C);
+    e.atomic = 1;
+    int32_t rc = launch_gemm(C, C, R * 49, 1, 9, splitk, la, lb, e, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(conv_dw_unpermute_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, dwp, dw, C);
+    ARFE_CHECK_LAUNCH();
+    int chunk = 32;
+    dim3 grid(C, cdiv(R, chunk));
+    hipLaunchKernelGGL(reduce_mid_kernel, grid, dim3(64), 0, st, dy, relu_out, db, R, dy_roi_stride, 49, chunk);
+    ARFE_CHECK_LAUNCH();
     return ARFE_OK;
 }
 

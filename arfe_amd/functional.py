@@ -14,6 +14,43 @@ from .hip import Pyramid, check, ptr, ptr_array, stream
 _i32 = ctypes.c_int32
 
 
+class _Probe:
+    """Optional HIP-event brackets around single kernel launches (bench.py's live roofline timing).
+    Events are recorded on the launch stream (torch's current stream == the stream handed to the C ABI)."""
+    enabled = False
+    records = {}
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if _Probe.enabled:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record(torch.cuda.current_stream())
+        return self
+
+    def __exit__(self, *exc):
+        if _Probe.enabled:
+            self.e1.record(torch.cuda.current_stream())
+            _Probe.records.setdefault(self.name, []).append((self.e0, self.e1))
+        return False
+
+
+def probe(name):
+    return _Probe(name)
+
+
+def probe_enable(flag=True):
+    _Probe.enabled = flag
+    _Probe.records = {}
+
+
+def probe_results_ms():
+    """name -> list of per-launch milliseconds (call after a device synchronise)."""
+    return {k: [a.elapsed_time(b) for a, b in v] for k, v in _Probe.records.items()}
+
+
 def _empty_like_levels(xs):
     return [torch.empty_like(x) for x in xs]
 
@@ -35,8 +72,9 @@ def fpn_gather_op(xs, refine_level, want_argmax=True):
     argmax = None
     if want_argmax and refine_level > 0:
         argmax = torch.empty(refine_level, B, C, hr, wr, dtype=torch.int32, device=xs[0].device)
-    check(hip.lib().arfe_fpn_gather_fwd(ctypes.byref(pyr), ptr_array(xs), ptr(m), ptr(argmax), stream()),
-          "arfe_fpn_gather_fwd")
+    with probe('fpn_gather_fwd'):
+        check(hip.lib().arfe_fpn_gather_fwd(ctypes.byref(pyr), ptr_array(xs), ptr(m), ptr(argmax), stream()),
+              "arfe_fpn_gather_fwd")
     return m, argmax
 
 
@@ -47,9 +85,10 @@ def fpn_gatemap_op(xs, w1, b1, w2, b2, refine_level=0):
     a = [torch.empty(x.shape[0], 1, x.shape[2], x.shape[3], device=dev) for x in xs]
     b = [torch.empty(x.shape[0], 1, x.shape[2], x.shape[3], device=dev) for x in xs]
     ws = _ws(hip.lib().arfe_fpn_gatemap_workspace_bytes(ctypes.byref(pyr)), dev)
-    check(hip.lib().arfe_fpn_gatemap_fwd(ctypes.byref(pyr), ptr_array(xs), ptr_array(w1), ptr_array(b1),
-                                         ptr_array(w2), ptr_array(b2), ptr_array(a), ptr_array(b), ptr(ws),
-                                         stream()), "arfe_fpn_gatemap_fwd")
+    with probe('fpn_gatemap_fwd'):
+        check(hip.lib().arfe_fpn_gatemap_fwd(ctypes.byref(pyr), ptr_array(xs), ptr_array(w1), ptr_array(b1),
+                                             ptr_array(w2), ptr_array(b2), ptr_array(a), ptr_array(b), ptr(ws),
+                                             stream()), "arfe_fpn_gatemap_fwd")
     return a, b
 
 
@@ -57,8 +96,9 @@ def fpn_scatter_op(xs, bsf, a, b, refine_level):
     hip.require_f32_cuda(*xs, bsf, *a, *b)
     pyr = Pyramid.of(xs, refine_level)
     outs = _empty_like_levels(xs)
-    check(hip.lib().arfe_fpn_scatter_fwd(ctypes.byref(pyr), ptr_array(xs), ptr(bsf), ptr_array(a), ptr_array(b),
-                                         ptr_array(outs), stream()), "arfe_fpn_scatter_fwd")
+    with probe('fpn_scatter_fwd'):
+        check(hip.lib().arfe_fpn_scatter_fwd(ctypes.byref(pyr), ptr_array(xs), ptr(bsf), ptr_array(a), ptr_array(b),
+                                             ptr_array(outs), stream()), "arfe_fpn_scatter_fwd")
     return outs
 
 
@@ -68,9 +108,10 @@ def fpn_scatter_bwd_op(gouts, bsf, a, b, refine_level):
     dpa = [torch.empty_like(t) for t in a]
     dpb = [torch.empty_like(t) for t in b]
     dbsf = torch.empty_like(bsf)
-    check(hip.lib().arfe_fpn_scatter_bwd(ctypes.byref(pyr), ptr_array(gouts), ptr(bsf), ptr_array(a), ptr_array(b),
-                                         ptr_array(dpa), ptr_array(dpb), ptr(dbsf), stream()),
-          "arfe_fpn_scatter_bwd")
+    with probe('fpn_scatter_bwd'):
+        check(hip.lib().arfe_fpn_scatter_bwd(ctypes.byref(pyr), ptr_array(gouts), ptr(bsf), ptr_array(a), ptr_array(b),
+                                             ptr_array(dpa), ptr_array(dpb), ptr(dbsf), stream()),
+              "arfe_fpn_scatter_bwd")
     return dpa, dpb, dbsf
 
 
@@ -78,9 +119,10 @@ def fpn_input_bwd_op(gouts, dpa, dpb, w1, w2, dm, argmax, refine_level):
     hip.require_f32_cuda(*gouts, *dpa, *dpb, *w1, *w2, dm)
     pyr = Pyramid.of(gouts, refine_level)
     dxs = _empty_like_levels(gouts)
-    check(hip.lib().arfe_fpn_input_bwd(ctypes.byref(pyr), ptr_array(gouts), ptr_array(dpa), ptr_array(dpb),
-                                       ptr_array(w1), ptr_array(w2), ptr(dm), ptr(argmax), ptr_array(dxs),
-                                       stream()), "arfe_fpn_input_bwd")
+    with probe('fpn_input_bwd'):
+        check(hip.lib().arfe_fpn_input_bwd(ctypes.byref(pyr), ptr_array(gouts), ptr_array(dpa), ptr_array(dpb),
+                                           ptr_array(w1), ptr_array(w2), ptr(dm), ptr(argmax), ptr_array(dxs),
+                                           stream()), "arfe_fpn_input_bwd")
     return dxs
 
 
@@ -93,9 +135,10 @@ def fpn_gate_wgrad_op(xs, dpa, dpb, refine_level=0):
     dw2 = [torch.empty(1, C, 3, 3, device=dev) for _ in range(n)]
     db1 = [torch.empty(1, device=dev) for _ in range(n)]
     db2 = [torch.empty(1, device=dev) for _ in range(n)]
-    check(hip.lib().arfe_fpn_gate_wgrad(ctypes.byref(pyr), ptr_array(xs), ptr_array(dpa), ptr_array(dpb),
-                                        ptr_array(dw1), ptr_array(db1), ptr_array(dw2), ptr_array(db2), stream()),
-          "arfe_fpn_gate_wgrad")
+    with probe('fpn_gate_wgrad'):
+        check(hip.lib().arfe_fpn_gate_wgrad(ctypes.byref(pyr), ptr_array(xs), ptr_array(dpa), ptr_array(dpb),
+                                            ptr_array(dw1), ptr_array(db1), ptr_array(dw2), ptr_array(db2), stream()),
+              "arfe_fpn_gate_wgrad")
     return dw1, db1, dw2, db2
 
 
@@ -113,9 +156,10 @@ def nonlocal_fwd_op(m, wt, bt, wp, bp, wg, bg, wo, bo):
     y = torch.empty(B, C, L, device=dev)
     bsf = torch.empty_like(m)
     ws = _ws(hip.lib().arfe_nonlocal_workspace_bytes(B, C, L), dev)
-    check(hip.lib().arfe_nonlocal_fwd(B, C, L, ptr(m), ptr(wt), ptr(bt), ptr(wp), ptr(bp), ptr(wg), ptr(bg), ptr(wo),
-                                      ptr(bo), ptr(tpg), ptr(P), ptr(y), ptr(bsf), ptr(ws), stream()),
-          "arfe_nonlocal_fwd")
+    with probe('nonlocal_fwd'):
+        check(hip.lib().arfe_nonlocal_fwd(B, C, L, ptr(m), ptr(wt), ptr(bt), ptr(wp), ptr(bp), ptr(wg), ptr(bg), ptr(wo),
+                                          ptr(bo), ptr(tpg), ptr(P), ptr(y), ptr(bsf), ptr(ws), stream()),
+              "arfe_nonlocal_fwd")
     return bsf, (tpg, P, y)
 
 
@@ -130,9 +174,10 @@ def nonlocal_bwd_op(dbsf, m, wt, wp, wg, wo, saved):
     dwt, dwp, dwg, dwo = (torch.empty_like(t) for t in (wt, wp, wg, wo))
     dbt, dbp, dbg, dbo = (torch.empty(C, device=dev) for _ in range(4))
     ws = _ws(hip.lib().arfe_nonlocal_workspace_bytes(B, C, L), dev)
-    check(hip.lib().arfe_nonlocal_bwd(B, C, L, ptr(dbsf), ptr(m), ptr(wt), ptr(wp), ptr(wg), ptr(wo), ptr(tpg), ptr(P),
-                                      ptr(y), ptr(dP), ptr(dm), ptr(dwt), ptr(dbt), ptr(dwp), ptr(dbp), ptr(dwg),
-                                      ptr(dbg), ptr(dwo), ptr(dbo), ptr(ws), stream()), "arfe_nonlocal_bwd")
+    with probe('nonlocal_bwd'):
+        check(hip.lib().arfe_nonlocal_bwd(B, C, L, ptr(dbsf), ptr(m), ptr(wt), ptr(wp), ptr(wg), ptr(wo), ptr(tpg), ptr(P),
+                                          ptr(y), ptr(dP), ptr(dm), ptr(dwt), ptr(dbt), ptr(dwp), ptr(dbp), ptr(dwg),
+                                          ptr(dbg), ptr(dwo), ptr(dbo), ptr(ws), stream()), "arfe_nonlocal_bwd")
     return dm, (dwt, dbt, dwp, dbp, dwg, dbg, dwo, dbo)
 
 
@@ -271,18 +316,29 @@ def roi_extract(feats, roi_sets, strides, finest_scale=56, pooled=7, sample_num=
 # AR-RFF head raw ops + autograd
 # ---------------------------------------------------------------------------------------------------------
 
-def conv3x3_fwd_op(x_view, roi_stride, R, C, w, b, relu, ws):
-    y = torch.empty(R, C, 7, 7, device=w.device)
-    check(hip.lib().arfe_conv3x3_fwd(R, C, x_view, roi_stride, ptr(w), ptr(b), int(relu), ptr(y), C * 49, ptr(ws),
-                                     stream()), "arfe_conv3x3_fwd")
+def conv3x3_pack_op(w):
+    C = w.shape[0]
+    packed = _ws(hip.lib().arfe_conv3x3_packed_bytes(C), w.device)
+    check(hip.lib().arfe_conv3x3_pack_weights(C, ptr(w), ptr(packed), stream()), "arfe_conv3x3_pack_weights")
+    return packed
+
+
+def conv3x3_fwd_op(x_view, roi_stride, R, C, packed, b, relu):
+    y = torch.empty(R, C, 7, 7, device=b.device)
+    with probe('conv3x3_fwd'):
+        check(hip.lib().arfe_conv3x3_fwd(R, C, x_view, roi_stride, ptr(packed), ptr(b), int(relu), ptr(y), C * 49,
+                                         stream()), "arfe_conv3x3_fwd")
     return y
 
 
-def conv3x3_bwd_op(x_view, x_roi_stride, R, C, w, dy, relu_out, dx_view, dx_roi_stride, ws):
+def conv3x3_bwd_op(x_view, x_roi_stride, R, C, w, packed, dy, relu_out, dx_view, dx_roi_stride, ws):
     dw = torch.empty_like(w)
     db = torch.empty(C, device=w.device)
-    check(hip.lib().arfe_conv3x3_bwd(R, C, x_view, x_roi_stride, ptr(w), ptr(dy), ptr(relu_out), C * 49, dx_view,
-                                     dx_roi_stride, ptr(dw), ptr(db), ptr(ws), stream()), "arfe_conv3x3_bwd")
+    with probe('conv3x3_bwd_data'):
+        check(hip.lib().arfe_conv3x3_bwd_data(R, C, ptr(packed), ptr(dy), ptr(relu_out), C * 49, dx_view, dx_roi_stride,
+                                              stream()), "arfe_conv3x3_bwd_data")
+    check(hip.lib().arfe_conv3x3_bwd_weight(R, C, x_view, x_roi_stride, ptr(dy), ptr(relu_out), C * 49, ptr(dw), ptr(db),
+                                            ptr(ws), stream()), "arfe_conv3x3_bwd_weight")
     return dw, db
 
 
@@ -318,24 +374,24 @@ class RFFHeadFunction(torch.autograd.Function):
         R, C3 = x.shape[0], x.shape[1]
         C = C3 // 3
         assert C3 == 3 * C and x.shape[2:] == (7, 7), "AR-RFF head expects [R, 3C, 7, 7]"
-        ws = _ws(hip.lib().arfe_conv3x3_workspace_bytes(C), x.device)
+        pk_wh, pk_hh, pk_f = conv3x3_pack_op(w_wh), conv3x3_pack_op(w_hh), conv3x3_pack_op(w_f)
         rs = C3 * 49
         base = x.data_ptr()
-        lw = conv3x3_fwd_op(base + 4 * C * 49, rs, R, C, w_wh, b_wh, True, ws)
-        lh = conv3x3_fwd_op(base + 4 * 2 * C * 49, rs, R, C, w_hh, b_hh, True, ws)
+        lw = conv3x3_fwd_op(base + 4 * C * 49, rs, R, C, pk_wh, b_wh, True)
+        lh = conv3x3_fwd_op(base + 4 * 2 * C * 49, rs, R, C, pk_hh, b_hh, True)
         z = torch.empty(R, C, 7, 7, device=x.device)
         check(hip.lib().arfe_rff_fuse_fwd(R, C, base, rs, ptr(lw), ptr(lh), ptr(z), stream()), "arfe_rff_fuse_fwd")
-        z2 = conv3x3_fwd_op(z.data_ptr(), C * 49, R, C, w_f, b_f, True, ws)
+        z2 = conv3x3_fwd_op(z.data_ptr(), C * 49, R, C, pk_f, b_f, True)
         f1 = linear_fwd_op(z2.view(R, -1), w1, b1, True)
         f2 = linear_fwd_op(f1, w2, b2, True)
         cls = linear_fwd_op(f2, wc, bc, False)
         reg = linear_fwd_op(f2, wr, br, False)
-        ctx.save_for_backward(x, w_wh, w_hh, w_f, w1, w2, wc, wr, lw, lh, z, z2, f1, f2)
+        ctx.save_for_backward(x, w_wh, w_hh, w_f, w1, w2, wc, wr, lw, lh, z, z2, f1, f2, pk_wh, pk_hh, pk_f)
         return cls, reg
 
     @staticmethod
     def backward(ctx, dcls, dreg):
-        x, w_wh, w_hh, w_f, w1, w2, wc, wr, lw, lh, z, z2, f1, f2 = ctx.saved_tensors
+        x, w_wh, w_hh, w_f, w1, w2, wc, wr, lw, lh, z, z2, f1, f2, pk_wh, pk_hh, pk_f = ctx.saved_tensors
         R, C3 = x.shape[0], x.shape[1]
         C = C3 // 3
         dev = x.device
@@ -348,13 +404,13 @@ class RFFHeadFunction(torch.autograd.Function):
         df1, dw2, db2 = linear_bwd_op(f1, w2, df2, f2)
         dz2, dw1, db1 = linear_bwd_op(z2.view(R, -1), w1, df1, f1)
         dz = torch.empty(R, C, 7, 7, device=dev)
-        dwf, dbf = conv3x3_bwd_op(z.data_ptr(), C * 49, R, C, w_f, dz2, z2, dz.data_ptr(), C * 49, ws)
+        dwf, dbf = conv3x3_bwd_op(z.data_ptr(), C * 49, R, C, w_f, pk_f, dz2, z2, dz.data_ptr(), C * 49, ws)
         dx = torch.empty_like(x)
         dl = torch.empty(R, C, 7, 7, device=dev)
         check(hip.lib().arfe_rff_fuse_bwd(R, C, x.data_ptr(), rs, ptr(lw), ptr(lh), ptr(dz), dx.data_ptr(), rs, ptr(dl),
                                           stream()), "arfe_rff_fuse_bwd")
-        dwwh, dbwh = conv3x3_bwd_op(x.data_ptr() + 4 * C * 49, rs, R, C, w_wh, dl, lw, dx.data_ptr() + 4 * C * 49, rs, ws)
-        dwhh, dbhh = conv3x3_bwd_op(x.data_ptr() + 8 * C * 49, rs, R, C, w_hh, dl, lh, dx.data_ptr() + 8 * C * 49, rs, ws)
+        dwwh, dbwh = conv3x3_bwd_op(x.data_ptr() + 4 * C * 49, rs, R, C, w_wh, pk_wh, dl, lw, dx.data_ptr() + 4 * C * 49, rs, ws)
+        dwhh, dbhh = conv3x3_bwd_op(x.data_ptr() + 8 * C * 49, rs, R, C, w_hh, pk_hh, dl, lh, dx.data_ptr() + 8 * C * 49, rs, ws)
         return dx, dwwh, dbwh, dwhh, dbhh, dwf, dbf, dw1, db1, dw2, db2, dwc, dbc, dwr, dbr
 
 

@@ -1,0 +1,197 @@
+#!/usr/bin/env python
+"""AR-FPN + AR-RFF forward+backward throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by the driver through torch.distributed.run, one rank per GPU, RCCL over xGMI)
+
+A step = one pass of the hot path over one batch of synthetic input, per GPU:
+    5-level 256-ch pyramid from a 1333x800 image (padded 1344x800), B = 2 images  -> AR-FPN (WFPNDualSpatial)
+    -> 3-RoI RoIAlign concat of R = 512*B RoIs -> AR-RFF head (MultiRoIsBBoxHead) -> backward of both
+    -> gradient all-reduce(mean) over ranks.
+Inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, exact fp32
+PEAK_HBM_GBS = 8000.0            # spec; ~6300 GB/s achievable by a float4 copy
+ARFPN_HBM_BYTES_PER_IMG = 458.4e6   # fwd 2 x 91.67 MB + bwd 3 x 91.67 MB
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=2, help='images per GPU (BASELINE config: bs=2)')
+    ap.add_argument('--rois-per-img', type=int, default=512)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-iters', type=int, default=3)
+    return ap.parse_args()
+
+
+def build_modules(dev):
+    import arfe_amd
+    torch.manual_seed(1234)     # identical parameters on every rank
+    neck = arfe_amd.build_neck(dict(type='WFPNDualSpatial', in_channels=256, num_levels=5))
+    neck.init_weights()
+    roi_head = arfe_amd.build_head(dict(
+        type='StandardRoIHead',
+        bbox_roi_extractor=dict(type='SingleRoIExtractor', roi_layer=dict(type='RoIAlign', out_size=7, sample_num=0),
+                                out_channels=256, featmap_strides=[4, 8, 16, 32, 64]),
+        bbox_head=dict(type='MultiRoIsBBoxHead', in_channels=256, fc_out_channels=1024, roi_feat_size=7,
+                       num_classes=80,
+                       bbox_coder=dict(type='DeltaXYWHBBoxCoder', target_means=[0., 0., 0., 0.],
+                                       target_stds=[0.1, 0.1, 0.2, 0.2]),
+                       reg_class_agnostic=False, loss_cls=dict(type='CrossEntropyLoss'), loss_bbox=dict(type='L1Loss'))))
+    roi_head.init_weights()
+    return neck.to(dev), roi_head.to(dev)
+
+
+def cpu_baseline(batch, rois_per_img, iters, neck_state, head_state):
+    """The oracle (CPU restatement, kind='port') on the host cores, same synthetic workload."""
+    from oracle import arfe_oracle as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    pn = {k: v.clone().requires_grad_(True) for k, v in neck_state.items()}
+    ph = {k: v.clone().requires_grad_(True) for k, v in head_state.items()}
+    xs = [x.requires_grad_(True) for x in O.synth_pyramid(batch, 256, seed=1234)]
+    rois = O.synth_rois(batch, rois_per_img, seed=1234)
+    g = torch.Generator().manual_seed(99)
+    c1 = torch.randn(rois.shape[0], 81, generator=g)
+    c2 = torch.randn(rois.shape[0], 320, generator=g)
+
+    def step():
+        for t in xs + list(pn.values()) + list(ph.values()):
+            t.grad = None
+        feats = O.arfpn_forward(xs, pn, 2)
+        cls, reg = O.rff_head(O.roi_extract3(feats, rois), ph)
+        torch.autograd.backward([cls, reg], [c1, c2])
+
+    step()   # warm-up
+    ts = []
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        step()
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    med = ts[len(ts) // 2]
+    return {"value": round(batch / med, 4), "unit": "imgs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{iters} timed + 1 warm-up fwd+bwd passes of the same workload (B={batch}, R={rois.shape[0]}), "
+                      f"median {med:.2f} s/step; oracle/arfe_oracle.py (torch-CPU fp32) + oracle C RoIAlign (1 thread)"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    dev = torch.device('cuda', local_rank)
+    torch.cuda.set_device(dev)
+
+    from arfe_amd import functional as Fn
+    from arfe_amd.dist import GradAllReducer
+    from oracle import arfe_oracle as O      # only the synthetic-input generators and (rank 0) the cpu_baseline leg
+
+    neck, roi_head = build_modules(dev)
+    neck_state = {k: v.detach().cpu().clone() for k, v in neck.state_dict().items()}
+    head_state = {k: v.detach().cpu().clone() for k, v in roi_head.bbox_head.state_dict().items()}
+    B, R = args.batch, args.batch * args.rois_per_img
+    xs = [x.to(dev).requires_grad_(True) for x in O.synth_pyramid(B, 256, seed=1234 + rank)]
+    rois = O.synth_rois(B, args.rois_per_img, seed=1234 + rank).to(dev)
+    g = torch.Generator().manual_seed(99 + rank)
+    cot_cls = torch.randn(R, 81, generator=g).to(dev)
+    cot_reg = torch.randn(R, 320, generator=g).to(dev)
+    # gradients become ready head-first, then the neck
+    reducer = GradAllReducer([list(roi_head.bbox_head.parameters()), list(neck.parameters())])
+
+    def step():
+        reducer.zero_grad()
+        for x in xs:
+            x.grad = None
+        feats = neck(xs)
+        res = roi_head._bbox_forward(feats, rois)
+        torch.autograd.backward([res['cls_score'], res['bbox_pred']], [cot_cls, cot_reg])
+        reducer.synchronize()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    Fn.probe_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    probes = Fn.probe_results_ms()
+    Fn.probe_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    if rank == 0:
+        imgs = world * B * args.steps
+        # dominant kernel: the implicit-GEMM 3x3 conv (gemm_f32_kernel<LoadRowMajorK, ConvGatherB, EpiConv>),
+        # 3 forward + 3 data-gradient launches per step, each 2*C*C*9 * R*49 flop
+        conv_ms = probes.get('conv3x3_fwd', []) + probes.get('conv3x3_bwd_data', [])
+        conv_flop = 2.0 * 256 * 256 * 9 * R * 49
+        avg_ms = sum(conv_ms) / max(len(conv_ms), 1)
+        ach = conv_flop / (avg_ms * 1e-3) / 1e12 if conv_ms else 0.0
+        fpn_keys = ['fpn_gather_fwd', 'fpn_gatemap_fwd', 'fpn_scatter_fwd', 'fpn_scatter_bwd', 'fpn_input_bwd',
+                    'fpn_gate_wgrad']
+        fpn_ms = sum(sum(probes.get(k, [])) for k in fpn_keys) / args.steps
+        hbm_gbs = ARFPN_HBM_BYTES_PER_IMG * B / (fpn_ms * 1e-3) / 1e9 if fpn_ms > 0 else 0.0
+        nl_ms = (sum(probes.get('nonlocal_fwd', [])) + sum(probes.get('nonlocal_bwd', []))) / args.steps
+        out = {
+            "metric": "imgs/s AR-FPN+AR-RFF fwd+bwd, 5-level 256-ch pyramid @1333x800",
+            "value": round(imgs / elapsed, 3), "unit": "imgs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "Faster R-CNN R50 AR-FPN + AR-RFF hot path (BASELINE configs[2]): WFPNDualSpatial "
+                                   "(refine_level 2) + 3-RoI RoIAlign + MultiRoIsBBoxHead, fwd+bwd + grad all-reduce",
+                       "per_gpu_batch": B, "global_batch": world * B, "rois_per_gpu": R, "channels": 256,
+                       "pyramid": "200x336,100x168,50x84,25x42,13x21", "parallelism": f"image-dp{world}"},
+            "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel<LoadRowMajorK,ConvGatherB,EpiConv> (3x3 conv 256->256 "
+                                                    "on [R,256,7,7], fwd + data-grad)",
+                         "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "flop_per_launch": conv_flop, "avg_launch_ms": round(avg_ms, 4), "launches": len(conv_ms)},
+            "roofline_hbm_stages": {"bound": "hbm", "stages": "AR-FPN gather+gate+scatter fwd/bwd (NonLocal excluded)",
+                                    "achieved": round(hbm_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                    "frac": round(hbm_gbs / PEAK_HBM_GBS, 4), "ms_per_step": round(fpn_ms, 4),
+                                    "algorithmic_bytes_per_img": ARFPN_HBM_BYTES_PER_IMG},
+            "stage_ms_per_step": {"arfpn_hbm_stages": round(fpn_ms, 4), "nonlocal_fwd_bwd": round(nl_ms, 4),
+                                  "conv3x3_fwd_and_dgrad": round(sum(conv_ms) / args.steps, 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(B, args.rois_per_img, args.cpu_iters, neck_state, head_state)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -141,18 +141,25 @@ int32_t arfe_roialign_bwd(const arfe_pyramid_t* pyr, float* const* dfeats, const
                           const float* gout, int64_t gout_roi_stride, void* stream);
 
 /* 3x3 conv, padding 1, on RoI features [R, C, 7, 7] (MultiBBoxHead wh_conv/hh_conv/final_conv,
- * bbox_heads/multirois_bbox_head.py:50-78,172-173,183): y = act(conv(x; w) + b).  x/y are addressed as
- * base + r*roi_stride + c*49 + p so a channel slice of the [R,3C,7,7] concat is passed without a copy.
- * workspace: arfe_conv3x3_workspace_bytes(C). */
-int64_t arfe_conv3x3_workspace_bytes(int32_t C);
-int32_t arfe_conv3x3_fwd(int32_t R, int32_t C, const float* x, int64_t x_roi_stride, const float* w,
-                         const float* b, int32_t relu, float* y, int64_t y_roi_stride, void* workspace,
-                         void* stream);
-/* dy_eff = relu_out ? dy * [relu_out > 0] : dy ; dx = conv^T(dy_eff), dw = x (*) dy_eff, db = sum dy_eff.
- * relu_out (the forward output, may be NULL) shares dy's addressing. dx may be NULL. */
-int32_t arfe_conv3x3_bwd(int32_t R, int32_t C, const float* x, int64_t x_roi_stride, const float* w,
-                         const float* dy, const float* relu_out, int64_t dy_roi_stride, float* dx,
-                         int64_t dx_roi_stride, float* dw, float* db, void* workspace, void* stream);
+ * bbox_heads/multirois_bbox_head.py:50-78,172-173,183) as an implicit GEMM on the matrix cores.
+ * Weights w [C,C,3,3] are re-laid once per optimizer step into `packed` (arfe_conv3x3_packed_bytes(C) bytes:
+ * [tap][co][ci] for the forward pass, [tap][ci][co] flipped for the data gradient).
+ * x / y / dy / dx are addressed as base + r*roi_stride + c*49 + p, so a channel slice of the [R,3C,7,7]
+ * concat is passed without a copy. */
+int64_t arfe_conv3x3_packed_bytes(int32_t C);
+int64_t arfe_conv3x3_workspace_bytes(int32_t C);   /* scratch of arfe_conv3x3_bwd_weight */
+int32_t arfe_conv3x3_pack_weights(int32_t C, const float* w, void* packed, void* stream);
+/* y = act(conv(x; w) + b) */
+int32_t arfe_conv3x3_fwd(int32_t R, int32_t C, const float* x, int64_t x_roi_stride, const void* packed,
+                         const float* b, int32_t relu, float* y, int64_t y_roi_stride, void* stream);
+/* dy_eff = relu_out ? dy * [relu_out > 0] : dy (relu_out = the forward output, shares dy's addressing).
+ * dx = conv^T(dy_eff) */
+int32_t arfe_conv3x3_bwd_data(int32_t R, int32_t C, const void* packed, const float* dy, const float* relu_out,
+                              int64_t dy_roi_stride, float* dx, int64_t dx_roi_stride, void* stream);
+/* dw = x (*) dy_eff  [C,C,3,3], db = sum dy_eff  [C] */
+int32_t arfe_conv3x3_bwd_weight(int32_t R, int32_t C, const float* x, int64_t x_roi_stride, const float* dy,
+                                const float* relu_out, int64_t dy_roi_stride, float* dw, float* db,
+                                void* workspace, void* stream);
 
 /* fusion (multirois_bbox_head.py:175-182): z = ori + ori * (lw + lh); ori is a slice (roi stride given),
  * lw, lh, z are dense [R,C,7,7]. */
