@@ -262,17 +262,24 @@ def roialign_fwd_op(feats, strides, rois, levels, out, chan_offset, pooled=7, sa
     hip.require_f32_cuda(*feats, rois, out)
     pyr = Pyramid.of(feats, 0)
     view = out[:, chan_offset:]
-    check(hip.lib().arfe_roialign_fwd(ctypes.byref(pyr), ptr_array(feats), _stride_array(strides), rois.shape[0],
+    with probe('roialign_fwd'):
+      check(hip.lib().arfe_roialign_fwd(ctypes.byref(pyr), ptr_array(feats), _stride_array(strides), rois.shape[0],
                                       ptr(rois), ptr(levels), pooled, sample_num, view.data_ptr(), out.stride(0),
                                       stream()), "arfe_roialign_fwd")
 
 
-def roialign_bwd_op(dfeats, strides, rois, levels, gout, chan_offset, pooled=7, sample_num=0):
+def roialign_bwd_op(shapes, strides, roi_sets, level_sets, gout, pooled=7, sample_num=0):
+    """d(feats) of all RoI sets at once; every element is written by the kernel (no zero-fill, no atomics)."""
+    dev = gout.device
+    dfeats = [torch.empty(shape, device=dev) for shape in shapes]
     pyr = Pyramid.of(dfeats, 0)
-    view = gout[:, chan_offset:]
-    check(hip.lib().arfe_roialign_bwd(ctypes.byref(pyr), ptr_array(dfeats), _stride_array(strides), rois.shape[0],
-                                      ptr(rois), ptr(levels), pooled, sample_num, view.data_ptr(), gout.stride(0),
-                                      stream()), "arfe_roialign_bwd")
+    nsets, R = len(roi_sets), roi_sets[0].shape[0]
+    ws = _ws(hip.lib().arfe_roialign_bwd_workspace_bytes(ctypes.byref(pyr), nsets, R), dev)
+    with probe('roialign_bwd'):
+        check(hip.lib().arfe_roialign_bwd(ctypes.byref(pyr), ptr_array(dfeats), _stride_array(strides), nsets, R,
+                                          ptr_array(roi_sets), ptr_array(level_sets), pooled, sample_num, ptr(gout),
+                                          gout.stride(0), ptr(ws), stream()), "arfe_roialign_bwd")
+    return dfeats
 
 
 class RoIExtractFunction(torch.autograd.Function):
@@ -302,9 +309,7 @@ class RoIExtractFunction(torch.autograd.Function):
         s = ctx.saved_tensors
         roi_sets, levels = s[:nsets], s[nsets:]
         gout = gout.contiguous()
-        dfeats = [torch.zeros(shape, device=gout.device) for shape in ctx.shapes]
-        for k in range(nsets):
-            roialign_bwd_op(dfeats, strides, roi_sets[k], levels[k], gout, k * C, pooled, sample_num)
+        dfeats = roialign_bwd_op(ctx.shapes, strides, list(roi_sets), list(levels), gout, pooled, sample_num)
         return (None, None, None, None, None, *([None] * nsets), *dfeats)
 
 

@@ -60,7 +60,8 @@ def build_modules(dev):
 def cpu_baseline(batch, rois_per_img, iters, neck_state, head_state):
     """The oracle (CPU restatement, kind='port') on the host cores, same synthetic workload."""
     from oracle import arfe_oracle as O
-    torch.set_num_threads(os.cpu_count() or 1)
+    # the 1-GPU box gives this job a 16-core CPU share (os.cpu_count() reports the whole host)
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
     pn = {k: v.clone().requires_grad_(True) for k, v in neck_state.items()}
     ph = {k: v.clone().requires_grad_(True) for k, v in head_state.items()}
     xs = [x.requires_grad_(True) for x in O.synth_pyramid(batch, 256, seed=1234)]

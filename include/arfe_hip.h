@@ -130,15 +130,20 @@ int32_t arfe_map_roi_levels(int32_t R, const float* rois, int32_t num_levels, fl
  * :107-191 fwd, :247-332 bwd; CUDA kernels src/cuda/roi_align_kernel_v2.cu:63-129,180-) fused with the
  * per-level dispatch of SingleRoIExtractor.forward (single_level.py:109-152): RoI k samples level levels[k]
  * with spatial scale 1/strides[level].  out is written at out + k*out_roi_stride + c*P*P (so three calls fill
- * the [R, 3C, 7, 7] concat of standard_roi_head.py:155 in place).  Returns ARFE_ERR_ARG for P != 7. */
+ * the [R, 3C, 7, 7] concat of standard_roi_head.py:155 in place). */
 int32_t arfe_roialign_fwd(const arfe_pyramid_t* pyr, const float* const* feats, const int32_t* strides,
                           int32_t R, const float* rois, const int64_t* levels, int32_t pooled,
                           int32_t sample_num, float* out, int64_t out_roi_stride, void* stream);
 
-/* dfeats[i] += RoIAlign^T(gout) (atomic accumulation: the CALLER zeroes dfeats before the first call). */
-int32_t arfe_roialign_bwd(const arfe_pyramid_t* pyr, float* const* dfeats, const int32_t* strides, int32_t R,
-                          const float* rois, const int64_t* levels, int32_t pooled, int32_t sample_num,
-                          const float* gout, int64_t gout_roi_stride, void* stream);
+/* dfeats[i] = sum over all `nsets` RoI sets of RoIAlign^T(gout slice of that set): every element of every
+ * dfeats[i] is WRITTEN exactly once (no atomics on the feature maps, no pre-zeroing).  Set s reads its upstream
+ * gradient at gout + k*gout_roi_stride + (s*C + c)*49 + p (the [R, nsets*C, 7, 7] concat gradient).
+ * RoIs are binned per 16x16 feature tile in `workspace` (arfe_roialign_bwd_workspace_bytes). pooled must be 7. */
+int64_t arfe_roialign_bwd_workspace_bytes(const arfe_pyramid_t* pyr, int32_t nsets, int32_t R);
+int32_t arfe_roialign_bwd(const arfe_pyramid_t* pyr, float* const* dfeats, const int32_t* strides, int32_t nsets,
+                          int32_t R, const float* const* rois, const int64_t* const* levels, int32_t pooled,
+                          int32_t sample_num, const float* gout, int64_t gout_roi_stride, void* workspace,
+                          void* stream);
 
 /* 3x3 conv, padding 1, on RoI features [R, C, 7, 7] (MultiBBoxHead wh_conv/hh_conv/final_conv,
  * bbox_heads/multirois_bbox_head.py:50-78,172-173,183) as an implicit GEMM on the matrix cores.

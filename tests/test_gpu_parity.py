@@ -225,6 +225,29 @@ def test_roialign_golden(Fn, dev):
     assert relerr(layer(d['feat1'].to(dev), rois), d['single_lvl1_sn2']) <= TOL
 
 
+def test_roialign_realistic_geometry_matches_oracle(Fn, O, dev):
+    """The bench's synthetic RoIs (16..512 px, clipped to 1344x800) and their enlarged sets on the full-size
+    pyramid geometry (12 channels): forward concat and the tile-binned backward against the C oracle."""
+    g = torch.Generator().manual_seed(8)
+    C = 12
+    feats_cpu = [torch.randn(2, C, h, w, generator=g) for h, w in O.PYRAMID_1333x800]
+    rois = O.synth_rois(2, 160, seed=5)
+    rois = torch.cat([rois, torch.tensor([[0, 0., 0., 1343., 799.], [1, 2., 790., 1340., 799.],
+                                          [1, 1300., 0., 1343., 799.], [0, 640., 400., 640., 400.]])])
+    fo = [f.clone().requires_grad_(True) for f in feats_cpu]
+    ref = O.roi_extract3(fo, rois)
+    cot = torch.randn(ref.shape, generator=g)
+    (ref * cot).sum().backward()
+    fd = [f.to(dev).requires_grad_(True) for f in feats_cpu]
+    rd = rois.to(dev)
+    h_r, w_r = Fn.make_rois_op(rd)
+    got = Fn.roi_extract(fd, [rd, w_r, h_r], O.STRIDES)
+    assert relerr(got, ref) <= TOL
+    (got * cot.to(dev)).sum().backward()
+    for i in range(5):
+        assert relerr(fd[i].grad, fo[i].grad if fo[i].grad is not None else torch.zeros_like(fo[i])) <= TOL_GRAD, i
+
+
 @pytest.mark.parametrize('name', ['rff_head_r8.npz', 'rff_head_r40.npz'])
 def test_rff_head_golden(Fn, dev, name):
     d = load_golden(name)
