@@ -1,0 +1,78 @@
+"""CPU, world_size 2, gloo: the image-parallel gradient exchange (arfe_amd/dist.py) that bench.py --gpus N uses."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from arfe_amd.dist import GradAllReducer
+    torch.manual_seed(0)
+    head = torch.nn.Linear(6, 4)
+    neck = torch.nn.Linear(4, 4)
+    frozen = torch.nn.Linear(2, 2)     # a bucket that receives no gradient must still stay in lockstep
+    red = GradAllReducer([list(head.parameters()), list(neck.parameters()), list(frozen.parameters())])
+    ok = True
+    for step in range(3):
+        red.zero_grad()
+        x = torch.full((2, 4), float(rank + 1 + step))        # each rank has its own "images"
+        y = head(torch.cat([neck(x), x[:, :2]], 1))
+        y.sum().backward()
+        red.synchronize()
+        # reference: average of the per-rank gradients, computed locally for both ranks
+        exp = []
+        for r in range(world):
+            h2, n2 = torch.nn.Linear(6, 4), torch.nn.Linear(4, 4)
+            h2.load_state_dict(head.state_dict()); n2.load_state_dict(neck.state_dict())
+            xr = torch.full((2, 4), float(r + 1 + step))
+            h2(torch.cat([n2(xr), xr[:, :2]], 1)).sum().backward()
+            exp.append([p.grad.clone() for p in list(h2.parameters()) + list(n2.parameters())])
+        mean = [sum(e[i] for e in exp) / world for i in range(len(exp[0]))]
+        got = [p.grad for p in list(head.parameters()) + list(neck.parameters())]
+        ok &= all(torch.allclose(g, m, atol=1e-6) for g, m in zip(got, mean))
+        ok &= all(p.grad.abs().max() == 0 for p in frozen.parameters())
+        # grads are views of the flat bucket (no flatten copies)
+        ok &= head.weight.grad.data_ptr() == red.buckets[0].flat.data_ptr()
+    # max-over-ranks timing reduction used by bench.py
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ok &= t.item() == float(world)
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_allreduce_world2_gloo():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_single_process_is_a_noop_reduce():
+    from arfe_amd.dist import GradAllReducer
+    lin = torch.nn.Linear(3, 2)
+    red = GradAllReducer([list(lin.parameters())])
+    red.zero_grad()
+    lin(torch.ones(1, 3)).sum().backward()
+    red.synchronize()
+    assert torch.allclose(lin.weight.grad, torch.ones(2, 3)) and red.world == 1

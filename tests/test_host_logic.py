@@ -1,0 +1,144 @@
+"""CPU: the plugin surface mirrors the reference (registry contract, ctor arguments, state_dict keys, init)."""
+import os
+
+import pytest
+import torch
+
+import arfe_amd
+from arfe_amd import hip
+
+
+def test_registry_contract():
+    assert 'WFPNDualSpatial' in arfe_amd.NECKS
+    for n in ('MultiBBoxHead', 'MultiRoIsBBoxHead', 'StandardRoIHead', 'BBoxHead'):
+        assert n in arfe_amd.HEADS
+    assert 'SingleRoIExtractor' in arfe_amd.ROI_EXTRACTORS
+    with pytest.raises(KeyError):
+        arfe_amd.build_neck(dict(type='NoSuchNeck'))
+    with pytest.raises(KeyError):
+        arfe_amd.build_neck(dict(in_channels=3))
+    # a LIST of cfgs composes into nn.Sequential (builder.py:13-20)
+    seq = arfe_amd.build_neck([dict(type='WFPNDualSpatial', in_channels=8, num_levels=5),
+                               dict(type='WFPNDualSpatial', in_channels=8, num_levels=5, refine_level=3)])
+    assert isinstance(seq, torch.nn.Sequential) and seq[1].refine_level == 3
+
+    R = arfe_amd.Registry('x')
+
+    @R.register_module
+    class A:
+        pass
+
+    @R.register_module()
+    class B:
+        pass
+
+    assert R.get('A') is A and R.get('B') is B
+    with pytest.raises(KeyError):
+        R.register_module(A)
+
+
+def test_neck_state_dict_and_init():
+    neck = arfe_amd.build_neck(dict(type='WFPNDualSpatial', in_channels=256, num_levels=5))
+    sd = neck.state_dict()
+    assert sum(v.numel() for v in sd.values()) == 286218
+    for i in range(5):
+        assert sd[f'reduce_convs.{i}.conv.weight'].shape == (1, 256, 3, 3)
+        assert sd[f'reduce_convs2.{i}.conv.bias'].shape == (1,)
+    for n in ('g', 'theta', 'phi', 'conv_out'):
+        assert sd[f'refine.{n}.conv.weight'].shape == (256, 256, 1, 1)
+    # NonLocal2D's own init zeroes conv_out; the neck's init_weights() overrides it with xavier-uniform (§3.3)
+    assert neck.refine.conv_out.conv.weight.abs().max() == 0
+    neck.init_weights()
+    w = neck.refine.conv_out.conv.weight
+    bound = (6.0 / 512) ** 0.5
+    assert 0 < w.abs().max() <= bound + 1e-6
+    assert all(v.abs().max() == 0 for k, v in neck.state_dict().items() if k.endswith('bias'))
+    with pytest.raises(AssertionError):
+        neck([torch.zeros(1, 256, 4, 4)] * 4)      # len(inputs) must equal num_levels (wfpn_dual_spatial.py:100)
+
+
+def test_head_state_dict_and_init():
+    head = arfe_amd.build_head(dict(
+        type='MultiRoIsBBoxHead', in_channels=256, fc_out_channels=1024, roi_feat_size=7, num_classes=80,
+        bbox_coder=dict(type='DeltaXYWHBBoxCoder', target_means=[0., 0., 0., 0.], target_stds=[0.1, 0.1, 0.2, 0.2]),
+        reg_class_agnostic=False, loss_cls=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0),
+        loss_bbox=dict(type='L1Loss', loss_weight=1.0)))
+    sd = head.state_dict()
+    assert sum(v.numel() for v in sd.values()) == 16076945
+    assert sd['wh_conv.conv.weight'].shape == (256, 256, 3, 3)
+    assert sd['shared_fcs.0.weight'].shape == (1024, 12544) and sd['shared_fcs.1.weight'].shape == (1024, 1024)
+    assert sd['fc_cls.weight'].shape == (81, 1024) and sd['fc_reg.weight'].shape == (320, 1024)
+    head.init_weights()
+    assert abs(head.fc_cls.weight.std().item() - 0.01) < 2e-3 and abs(head.fc_reg.weight.std().item() - 0.001) < 2e-4
+    with pytest.raises(NotImplementedError):
+        arfe_amd.build_head(dict(type='MultiBBoxHead', num_shared_convs=1, num_shared_fcs=2))
+
+
+def test_roi_head_builds_from_cfg_dicts():
+    rh = arfe_amd.build_head(dict(
+        type='StandardRoIHead',
+        bbox_roi_extractor=dict(type='SingleRoIExtractor', roi_layer=dict(type='RoIAlign', out_size=7, sample_num=0),
+                                out_channels=256, featmap_strides=[4, 8, 16, 32, 64]),
+        bbox_head=dict(type='MultiRoIsBBoxHead', in_channels=256, fc_out_channels=1024, roi_feat_size=7,
+                       num_classes=80)))
+    assert rh.bbox_roi_extractor.num_inputs == 5 and rh.bbox_roi_extractor.finest_scale == 56
+    assert len(rh.bbox_roi_extractor.roi_layers) == 5 and rh.bbox_roi_extractor.roi_layers[2].spatial_scale == 1 / 16
+
+
+def test_product_path_refuses_cpu_tensors():
+    """No CPU/PyTorch fallback: a CPU tensor is an error, never a silent slow path."""
+    neck = arfe_amd.build_neck(dict(type='WFPNDualSpatial', in_channels=4, num_levels=2, refine_level=0))
+    with pytest.raises(hip.ArfeHipError):
+        neck([torch.zeros(1, 4, 4, 4), torch.zeros(1, 4, 2, 2)])
+
+
+def test_product_package_never_imports_the_oracle():
+    import glob
+    from conftest import ROOT
+    for f in glob.glob(os.path.join(ROOT, 'arfe_amd', '**', '*.py'), recursive=True):
+        src = open(f).read()
+        assert 'oracle' not in src, f"{f} references the oracle"
+
+
+def test_config_loader(tmp_path):
+    base = tmp_path / 'base.py'
+    base.write_text("model = dict(type='FasterRCNN', neck=dict(type='FPN', in_channels=[256, 512], out_channels=256),\n"
+                    "             roi_head=dict(type='StandardRoIHead', bbox_head=dict(type='Shared2FCBBoxHead', n=1)))\n"
+                    "lr = 0.02\n")
+    child = tmp_path / 'child.py'
+    child.write_text("_base_ = './base.py'\n"
+                     "model = dict(neck=[dict(type='FPN', in_channels=[256, 512], out_channels=256, num_outs=5),\n"
+                     "                   dict(type='WFPNDualSpatial', in_channels=256, num_levels=5)],\n"
+                     "             roi_head=dict(bbox_head=dict(_delete_=True, type='MultiRoIsBBoxHead', in_channels=256)))\n")
+    cfg = arfe_amd.Config.fromfile(str(child))
+    assert cfg.lr == 0.02 and cfg.model.type == 'FasterRCNN'
+    assert cfg.model.neck[1].type == 'WFPNDualSpatial'
+    assert cfg.model.roi_head.bbox_head == dict(type='MultiRoIsBBoxHead', in_channels=256)   # _delete_ replaced it
+    assert cfg.model.roi_head.type == 'StandardRoIHead'
+    cfg.merge_from_dict({'model.neck': None, 'lr': 0.01})
+    assert cfg.lr == 0.01 and cfg.model.neck is None
+
+
+REF = '/root/reference/configs'
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason='reference configs exist only in the build container')
+def test_reference_configs_load_unchanged():
+    import warnings
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        cfg = arfe_amd.Config.fromfile(os.path.join(REF, 'mytrain', 'faster_rcnn_r50_drfpn_drrff+fac_1x_coco.py'))
+    assert any('stray' in str(x.message) for x in w)           # the flagship config's back-tick is flagged
+    assert cfg.model.neck[1] == dict(type='WFPNDualSpatial', in_channels=256, num_levels=5)
+    neck = arfe_amd.build_neck(cfg.model.neck[1])
+    assert neck.refine_level == 2
+    roi_head = arfe_amd.build_head(cfg.model.roi_head)
+    assert type(roi_head.bbox_head).__name__ == 'MultiRoIsBBoxHead'
+    assert roi_head.bbox_roi_extractor.featmap_strides == [4, 8, 16, 32, 64]
+    for rel in ('faster_rcnn/faster_rcnn_r50_fpn_1x_coco.py', 'cascade_rcnn/cascade_rcnn_r50_fpn_1x_coco.py',
+                'libra_rcnn/libra_faster_rcnn_r50_fpn_1x_coco.py'):
+        c = arfe_amd.Config.fromfile(os.path.join(REF, rel))
+        assert 'model' in c and c.model.type in ('FasterRCNN', 'CascadeRCNN')
+    libra = arfe_amd.Config.fromfile(os.path.join(REF, 'libra_rcnn', 'libra_faster_rcnn_r50_fpn_1x_coco.py'))
+    wf = [n for n in libra.model.neck if n['type'] == 'WFPNDualSpatial'][0]
+    assert arfe_amd.build_neck(wf).refine_level == wf.get('refine_level', 2)
