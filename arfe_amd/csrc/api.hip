@@ -1,5 +1,6 @@
 // C-ABI plumbing: error strings, version, argument validation shared by all entry points.
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "common.hpp"
 
@@ -12,6 +13,15 @@ void set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+bool gemm_use_f32() {
+    static int cached = -1;           // process-level switch, read once: ARFE_GEMM_F32=1 -> exact-fp32 MFMA
+    if (cached < 0) {
+        const char* e = getenv("ARFE_GEMM_F32");
+        cached = (e && e[0] == '1') ? 1 : 0;
+    }
+    return cached == 1;
 }
 
 int32_t check_pyramid(const arfe_pyramid_t* p) {

@@ -91,6 +91,7 @@ static inline Levels to_levels(const arfe_pyramid_t* p) {
     return l;
 }
 int32_t check_pyramid(const arfe_pyramid_t* p);
+bool gemm_use_f32();
 
 template <int N>
 struct PtrArray { const float* p[N]; };

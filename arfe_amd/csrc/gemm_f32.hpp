@@ -41,6 +41,19 @@ struct LoadRowMajorK {   // element(i, k) = p[z*sz + kb*skb + i*ld + k]     (k c
     __device__ __forceinline__ float operator()(int z, int kb, int i, int k) const {
         return (i < rows && k < K) ? p[z * sz + kb * skb + (int64_t)i * ld + k] : 0.f;
     }
+    // 8 consecutive k of one row: two 16-byte loads when the octet is inside the matrix
+    __device__ __forceinline__ void load8(int z, int kb, int i, int k0, float (&v)[8]) const {
+        if (i < rows && k0 + 7 < K) {
+            const float* q = p + z * sz + kb * skb + (int64_t)i * ld + k0;
+            const float4_u a = *reinterpret_cast<const float4_u*>(q);
+            const float4_u b = *reinterpret_cast<const float4_u*>(q + 4);
+            v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+            v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (*this)(z, kb, i, k0 + j);
+        }
+    }
 };
 struct LoadRowMajorI {   // element(i, k) = p[z*sz + kb*skb + k*ld + i]     (i contiguous)
     const float* p; int64_t sz, skb; int64_t ld; int rows, K;

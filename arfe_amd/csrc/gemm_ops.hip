@@ -1,6 +1,6 @@
 // Dense contractions of the AR path on the exact-fp32 MFMA GEMM (gemm_f32.hpp):
 //   NonLocal2D refine fwd/bwd, AR-RFF 3x3 convs (implicit GEMM) fwd/bwd, nn.Linear fwd/bwd.
-#include "gemm_f32.hpp"
+#include "gemm_bf16x3.hpp"
 
 namespace arfe {
 
@@ -255,7 +255,7 @@ static inline EpiPlain epi_plain(float* c, int64_t sz, int64_t ld) {
 template <class LA, class LB>
 static inline int32_t gemm_autosplit(int M, int N, int K, int kb, int batch, LA la, LB lb, EpiPlain e,
                                      size_t zero_elems, hipStream_t st) {
-    int splitk = (e.relu || e.accumulate) ? 1 : pick_splitk(M, N, batch, (kb < 1 ? 1 : kb) * cdiv(K, GEMM_BK));
+    int splitk = (e.relu || e.accumulate) ? 1 : pick_splitk(M, N, batch, (kb < 1 ? 1 : kb) * cdiv(K, gemm_bk()));
     if (splitk > 1) {
         if (hipMemsetAsync(e.c, 0, sizeof(float) * zero_elems, st) != hipSuccess) {
             set_error("gemm: memset failed");
@@ -263,7 +263,7 @@ static inline int32_t gemm_autosplit(int M, int N, int K, int kb, int batch, LA 
         }
         e.atomic = 1;
     }
-    return launch_gemm(M, N, K, kb, batch, splitk, la, lb, e, st);
+    return launch_gemm_auto(M, N, K, kb, batch, splitk, la, lb, e, st);
 }
 
 }  // namespace arfe
@@ -282,7 +282,7 @@ extern "C" int32_t arfe_linear_fwd(int32_t R, int32_t in_f, int32_t out_f, const
     // y[R,out] = x[R,in] . w[out,in]^T : A = x (k contiguous), B(n,k) = w[n*in + k] (k contiguous)
     LoadRowMajorK la{x, 0, 0, in_f, R, in_f};
     LoadRowMajorK lb{w, 0, 0, in_f, out_f, in_f};
-    int ksteps = cdiv(in_f, GEMM_BK);
+    int ksteps = cdiv(in_f, gemm_bk());
     int splitk = pick_splitk(R, out_f, 1, ksteps);
     EpiPlain e = epi_plain(y, 0, out_f);
     e.bias_n = b;
@@ -293,7 +293,7 @@ extern "C" int32_t arfe_linear_fwd(int32_t R, int32_t in_f, int32_t out_f, const
             return ARFE_ERR_LAUNCH;
         }
         e.atomic = 1;
-        int32_t rc = launch_gemm(R, out_f, in_f, 1, 1, splitk, la, lb, e, st);
+        int32_t rc = launch_gemm_auto(R, out_f, in_f, 1, 1, splitk, la, lb, e, st);
         if (rc) return rc;
         if (relu) {
             int64_t n = (int64_t)R * out_f;
@@ -303,7 +303,7 @@ extern "C" int32_t arfe_linear_fwd(int32_t R, int32_t in_f, int32_t out_f, const
         return ARFE_OK;
     }
     e.relu = relu;
-    return launch_gemm(R, out_f, in_f, 1, 1, 1, la, lb, e, st);
+    return launch_gemm_auto(R, out_f, in_f, 1, 1, 1, la, lb, e, st);
 }
 
 extern "C" int32_t arfe_linear_bwd(int32_t R, int32_t in_f, int32_t out_f, const float* x, const float* w,
@@ -323,7 +323,7 @@ extern "C" int32_t arfe_linear_bwd(int32_t R, int32_t in_f, int32_t out_f, const
         // dx[R,in] = dy_eff[R,out] . w[out,in] : A = dy (k=out contiguous, masked), B(n=in,k=out) = w[k*in + n]
         LoadMaskedK la{dy, relu_out, out_f, R, out_f};
         LoadRowMajorI lb{w, 0, 0, in_f, in_f, out_f};
-        int splitk = pick_splitk(R, in_f, 1, cdiv(out_f, GEMM_BK));
+        int splitk = pick_splitk(R, in_f, 1, cdiv(out_f, gemm_bk()));
         EpiPlain e = epi_plain(dx, 0, in_f);
         if (splitk > 1) {
             if (!accumulate_dx && hipMemsetAsync(dx, 0, sizeof(float) * (size_t)R * in_f, st) != hipSuccess)
@@ -332,17 +332,17 @@ extern "C" int32_t arfe_linear_bwd(int32_t R, int32_t in_f, int32_t out_f, const
         } else {
             e.accumulate = accumulate_dx;
         }
-        rc = launch_gemm(R, in_f, out_f, 1, 1, splitk, la, lb, e, st);
+        rc = launch_gemm_auto(R, in_f, out_f, 1, 1, splitk, la, lb, e, st);
         if (rc) return rc;
     }
     if (dw) {
         // dw[out,in] = dy_eff^T[out,R] . x[R,in] : A(m=out,k=r) = dy[k*out + m] (m contiguous), B(n=in,k=r) = x[k*in+n]
         LoadMaskedI la{dy, relu_out, out_f, out_f, R};
         LoadRowMajorI lb{x, 0, 0, in_f, in_f, R};
-        int splitk = pick_splitk(out_f, in_f, 1, cdiv(R, GEMM_BK));
+        int splitk = pick_splitk(out_f, in_f, 1, cdiv(R, gemm_bk()));
         EpiPlain e = epi_plain(dw, 0, in_f);
         e.atomic = splitk > 1;
-        rc = launch_gemm(out_f, in_f, R, 1, 1, splitk, la, lb, e, st);
+        rc = launch_gemm_auto(out_f, in_f, R, 1, 1, splitk, la, lb, e, st);
         if (rc) return rc;
     }
     if (db) {
@@ -384,7 +384,7 @@ extern "C" int32_t arfe_conv3x3_fwd(int32_t R, int32_t C, const float* x, int64_
     LoadRowMajorK la{wp, 0, (int64_t)C * C, C, C, C};     // A(m=co,k=ci) for tap kb
     ConvGatherB lb{x, nullptr, x_roi_stride, 0, R * 49, C};
     EpiConv e{y, y_roi_stride, b, relu};
-    return launch_gemm(C, R * 49, C, 9, 1, 1, la, lb, e, as_stream(stream));
+    return launch_gemm_auto(C, R * 49, C, 9, 1, 1, la, lb, e, as_stream(stream));
 }
 
 extern "C" int32_t arfe_conv3x3_bwd_data(int32_t R, int32_t C, const void* packed, const float* dy,
@@ -397,7 +397,7 @@ extern "C" int32_t arfe_conv3x3_bwd_data(int32_t R, int32_t C, const void* packe
     LoadRowMajorK la{wd, 0, (int64_t)C * C, C, C, C};      // A(m=ci,k=co) = w[co][ci][8-tap]
     ConvGatherB lb{dy, relu_out, dy_roi_stride, dy_roi_stride, R * 49, C};
     EpiConv e{dx, dx_roi_stride, nullptr, 0};
-    return launch_gemm(C, R * 49, C, 9, 1, 1, la, lb, e, as_stream(stream));
+    return launch_gemm_auto(C, R * 49, C, 9, 1, 1, la, lb, e, as_stream(stream));
 }
 
 extern "C" int32_t arfe_conv3x3_bwd_weight(int32_t R, int32_t C, const float* x, int64_t x_roi_stride,
@@ -416,11 +416,11 @@ extern "C" int32_t arfe_conv3x3_bwd_weight(int32_t R, int32_t C, const float* x,
     if (hipMemsetAsync(dwp, 0, sizeof(float) * (size_t)total, st) != hipSuccess) return ARFE_ERR_LAUNCH;
     WgradA la{dy, relu_out, dy_roi_stride, C, R * 49};
     WgradB lb{x, x_roi_stride, C, R * 49};
-    int ksteps = cdiv(R * 49, GEMM_BK);
+    int ksteps = cdiv(R * 49, gemm_bk());
     int splitk = pick_splitk(C, C, 9, ksteps);
     EpiPlain e = epi_plain(dwp, (int64_t)C * C, C);
     e.atomic = 1;
-    int32_t rc = launch_gemm(C, C, R * 49, 1, 9, splitk, la, lb, e, st);
+    int32_t rc = launch_gemm_auto(C, C, R * 49, 1, 9, splitk, la, lb, e, st);
     if (rc) return rc;
     hipLaunchKernelGGL(conv_dw_unpermute_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, dwp, dw, C);
     ARFE_CHECK_LAUNCH();
@@ -462,14 +462,14 @@ extern "C" int32_t arfe_nonlocal_fwd(int32_t B, int32_t C, int32_t L, const floa
         LoadRowMajorI lb{m, CL, 0, L, L, C};
         EpiPlain e = epi_plain(tpg, 3 * CL, L);
         e.bias_m = bcat;
-        rc = launch_gemm(3 * C, L, C, 1, B, 1, la, lb, e, st);
+        rc = launch_gemm_auto(3 * C, L, C, 1, B, 1, la, lb, e, st);
         if (rc) return rc;
     }
     {   // S[z][i][j] = sum_c theta[c][i] phi[c][j]
         LoadRowMajorI la{tpg, 3 * CL, 0, L, L, C};
         LoadRowMajorI lb{tpg + CL, 3 * CL, 0, L, L, C};
         EpiPlain e = epi_plain(P, LL, L);
-        rc = launch_gemm(L, L, C, 1, B, 1, la, lb, e, st);
+        rc = launch_gemm_auto(L, L, C, 1, B, 1, la, lb, e, st);
         if (rc) return rc;
     }
     hipLaunchKernelGGL(nl_softmax_rows_kernel, dim3(B * L), dim3(256), 0, st, P, L);
@@ -487,7 +487,7 @@ extern "C" int32_t arfe_nonlocal_fwd(int32_t B, int32_t C, int32_t L, const floa
         EpiPlain e = epi_plain(bsf, CL, L);
         e.bias_m = b_out;
         e.residual = m;
-        rc = launch_gemm(C, L, C, 1, B, 1, la, lb, e, st);
+        rc = launch_gemm_auto(C, L, C, 1, B, 1, la, lb, e, st);
         if (rc) return rc;
     }
     return ARFE_OK;
@@ -518,13 +518,13 @@ extern "C" int32_t arfe_nonlocal_bwd(int32_t B, int32_t C, int32_t L, const floa
     if (hipMemsetAsync(dw_out, 0, sizeof(float) * (size_t)C * C, st) != hipSuccess) return ARFE_ERR_LAUNCH;
     if (hipMemsetAsync(db_out, 0, sizeof(float) * (size_t)C, st) != hipSuccess) return ARFE_ERR_LAUNCH;
     int32_t rc;
-    const int kstepsL = cdiv(L, GEMM_BK);
+    const int kstepsL = cdiv(L, gemm_bk());
     {   // dw_out[co][ci] = sum_{z,l} dbsf[z][co][l] y[z][ci][l]   (k-batched over images, split-K)
         LoadRowMajorK la{dbsf, 0, CL, L, C, L};
         LoadRowMajorK lb{y, 0, CL, L, C, L};
         EpiPlain e = epi_plain(dw_out, 0, C);
         e.atomic = 1;
-        rc = launch_gemm(C, C, L, B, 1, pick_splitk(C, C, 1, B * kstepsL), la, lb, e, st);
+        rc = launch_gemm_auto(C, C, L, B, 1, pick_splitk(C, C, 1, B * kstepsL), la, lb, e, st);
         if (rc) return rc;
         dim3 grid(C, B);
         hipLaunchKernelGGL(reduce_mid_kernel, grid, dim3(256), 0, st, dbsf, (const float*)nullptr, db_out, B, CL, L, 1);
@@ -534,14 +534,14 @@ extern "C" int32_t arfe_nonlocal_bwd(int32_t B, int32_t C, int32_t L, const floa
         LoadRowMajorI la{w_out, 0, 0, C, C, C};
         LoadRowMajorI lb{dbsf, CL, 0, L, L, C};
         EpiPlain e = epi_plain(dy, CL, L);
-        rc = launch_gemm(C, L, C, 1, B, 1, la, lb, e, st);
+        rc = launch_gemm_auto(C, L, C, 1, B, 1, la, lb, e, st);
         if (rc) return rc;
     }
     {   // dP[z][i][j] = sum_c dy[c][i] g[c][j]
         LoadRowMajorI la{dy, CL, 0, L, L, C};
         LoadRowMajorI lb{tpg + 2 * CL, 3 * CL, 0, L, L, C};
         EpiPlain e = epi_plain(dP, LL, L);
-        rc = launch_gemm(L, L, C, 1, B, 1, la, lb, e, st);
+        rc = launch_gemm_auto(L, L, C, 1, B, 1, la, lb, e, st);
         if (rc) return rc;
     }
     {   // dg[z][c][j] = sum_i dy[c][i] P[i][j]   (before dP is overwritten nothing depends on order; P is read-only)
@@ -580,7 +580,7 @@ extern "C" int32_t arfe_nonlocal_bwd(int32_t B, int32_t C, int32_t L, const floa
         LoadRowMajorK lb{m, 0, CL, L, C, L};
         EpiPlain e = epi_plain(dwcat, 0, C);
         e.atomic = 1;
-        rc = launch_gemm(3 * C, C, L, B, 1, pick_splitk(3 * C, C, 1, B * kstepsL), la, lb, e, st);
+        rc = launch_gemm_auto(3 * C, C, L, B, 1, pick_splitk(3 * C, C, 1, B * kstepsL), la, lb, e, st);
         if (rc) return rc;
         dim3 grid(3 * C, B);
         hipLaunchKernelGGL(reduce_mid_kernel, grid, dim3(256), 0, st, dtpg, (const float*)nullptr, dbcat, B, 3 * CL, L, 1);

@@ -22,7 +22,8 @@ sys.path.insert(0, ROOT)
 import torch
 import torch.distributed as dist
 
-PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, exact fp32
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, exact fp32 (ARFE_GEMM_F32=1)
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # dense bf16 MFMA; the default contractions issue 3 bf16 MFMAs per fp32 product
 PEAK_HBM_GBS = 8000.0            # spec; ~6300 GB/s achievable by a float4 copy
 ARFPN_HBM_BYTES_PER_IMG = 458.4e6   # fwd 2 x 91.67 MB + bwd 3 x 91.67 MB
 
@@ -165,19 +166,25 @@ def main():
         fpn_ms = sum(sum(probes.get(k, [])) for k in fpn_keys) / args.steps
         hbm_gbs = ARFPN_HBM_BYTES_PER_IMG * B / (fpn_ms * 1e-3) / 1e9 if fpn_ms > 0 else 0.0
         nl_ms = (sum(probes.get('nonlocal_fwd', [])) + sum(probes.get('nonlocal_bwd', []))) / args.steps
+        f32_mode = os.environ.get('ARFE_GEMM_F32', '0') == '1'
+        peak = PEAK_F32_MFMA_TFLOPS if f32_mode else PEAK_BF16_MFMA_TFLOPS
         out = {
             "metric": "imgs/s AR-FPN+AR-RFF fwd+bwd, 5-level 256-ch pyramid @1333x800",
             "value": round(imgs / elapsed, 3), "unit": "imgs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if f32_mode else "f32 (dense contractions as bf16x3 split MFMA, fp32 accumulate)",
+            "data": "synthetic",
             "config": {"workload": "Faster R-CNN R50 AR-FPN + AR-RFF hot path (BASELINE configs[2]): WFPNDualSpatial "
                                    "(refine_level 2) + 3-RoI RoIAlign + MultiRoIsBBoxHead, fwd+bwd + grad all-reduce",
                        "per_gpu_batch": B, "global_batch": world * B, "rois_per_gpu": R, "channels": 256,
                        "pyramid": "200x336,100x168,50x84,25x42,13x21", "parallelism": f"image-dp{world}"},
-            "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel<LoadRowMajorK,ConvGatherB,EpiConv> (3x3 conv 256->256 "
-                                                    "on [R,256,7,7], fwd + data-grad)",
-                         "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "roofline": {"bound": "mfma",
+                         "kernel": ("gemm_f32_kernel" if f32_mode else "gemm_bf16x3_kernel") +
+                                   "<LoadRowMajorK,ConvGatherB,EpiConv> (3x3 conv 256->256 on [R,256,7,7], fwd + data-grad)",
+                         "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(ach / peak, 4), "traffic": None,
+                         "mfma_flop_per_algorithmic_flop": 1 if f32_mode else 3,
                          "flop_per_launch": conv_flop, "avg_launch_ms": round(avg_ms, 4), "launches": len(conv_ms)},
             "roofline_hbm_stages": {"bound": "hbm", "stages": "AR-FPN gather+gate+scatter fwd/bwd (NonLocal excluded)",
                                     "achieved": round(hbm_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",

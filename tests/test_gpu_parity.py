@@ -1,8 +1,9 @@
 """GPU parity: every HIP stage (called through the C ABI, arfe_amd.functional) against the CPU oracle on the
 same seeded inputs, and against the golden vectors generated from the reference (tests/golden).
 
-Tolerance: north_star asks for 1e-3 relative in fp32 (max|a-b|/max|b|); the kernels are exact-fp32 so the
-asserts are set tighter (TOL) to catch indexing bugs, bit-exact for integer/index results."""
+Tolerance: north_star asks for 1e-3 relative in fp32 (max|a-b|/max|b|).  The streaming kernels are exact fp32
+and the dense contractions run as bf16x3 split MFMA (~1e-5 relative), so the asserts are set 3-10x tighter than
+the north-star bound (TOL / TOL_GRAD) to catch indexing bugs; integer/index results must be bit-exact."""
 import pytest
 import torch
 
@@ -10,8 +11,8 @@ from conftest import load_golden, relerr
 
 pytestmark = pytest.mark.gpu
 
-TOL = 2e-5          # exact fp32 arithmetic, different summation order
-TOL_GRAD = 1e-4     # gradients (atomics, long reductions)
+TOL = 1e-4          # fp32 streaming kernels are ~1e-6; the bf16x3 split-MFMA contractions ~1e-5 per op
+TOL_GRAD = 3e-4     # gradients (chains of contractions, atomics, long reductions)
 NORTH_STAR_TOL = 1e-3
 
 
@@ -285,7 +286,7 @@ def test_end_to_end_golden_through_plugin_surface(dev):
         assert relerr(feats[i], d[f'feat{i}']) <= TOL, i
     res = roi_head._bbox_forward(feats, d['rois'].to(dev))
     assert relerr(res['bbox_feats'], d['bbox_feats']) <= TOL
-    assert relerr(res['cls_score'], d['cls']) <= 5e-5 and relerr(res['bbox_pred'], d['reg']) <= 5e-5
+    assert relerr(res['cls_score'], d['cls']) <= TOL and relerr(res['bbox_pred'], d['reg']) <= TOL
     ((res['cls_score'] * d['cot_cls'].to(dev)).sum() + (res['bbox_pred'] * d['cot_reg'].to(dev)).sum()).backward()
     for i in range(5):
         assert relerr(xs[i].grad, d[f'dx{i}']) <= TOL_GRAD, i
