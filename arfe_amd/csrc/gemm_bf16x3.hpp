@@ -21,21 +21,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int XB_BK = 32;
 constexpr int XB_LD = 40;   // bf16 elements per LDS row (32 + 8 pad)
 
-// generic octet load: 8 scalar functor calls (always correct); loaders may provide a faster `load8`
-template <class L, class = void>
-struct Octet {
-    static __device__ __forceinline__ void load(const L& l, int z, int kb, int row, int k0, float (&v)[8]) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = l(z, kb, row, k0 + j);
-    }
-};
-template <class L>
-struct Octet<L, decltype((void)&L::load8)> {
-    static __device__ __forceinline__ void load(const L& l, int z, int kb, int row, int k0, float (&v)[8]) {
-        l.load8(z, kb, row, k0, v);
-    }
-};
-
 __device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -88,14 +73,21 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmDims d, LA la, 
         if (LB::kfast) { b_oct[i] = tid & 3; b_row[i] = (tid >> 2) + 64 * i; }
         else           { b_row[i] = tid & 127; b_oct[i] = (tid >> 7) + 2 * i; }
     }
+    typename LA::Row arow[2];
+    typename LB::Row brow[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        arow[i] = la.row(z, m0 + a_row[i]);
+        brow[i] = lb.row(z, n0 + b_row[i]);
+    }
     float ra[2][8], rb[2][8];
     auto fetch = [&](int step) {
         const int kb = step / ksteps_per_kb;
         const int k0 = (step - kb * ksteps_per_kb) * XB_BK;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) Octet<LA>::load(la, z, kb, m0 + a_row[i], k0 + 8 * a_oct[i], ra[i]);
+        for (int i = 0; i < 2; ++i) la.load8(arow[i], z, kb, k0 + 8 * a_oct[i], ra[i]);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) Octet<LB>::load(lb, z, kb, n0 + b_row[i], k0 + 8 * b_oct[i], rb[i]);
+        for (int i = 0; i < 2; ++i) lb.load8(brow[i], z, kb, k0 + 8 * b_oct[i], rb[i]);
     };
     auto stash = [&]() {
 #pragma unroll
@@ -168,8 +160,8 @@ bool gemm_use_f32();
 
 template <class LA, class LB, class EPI>
 static inline int32_t launch_gemm_auto(int M, int N, int K, int kb_count, int batch, int splitk, LA la, LB lb, EPI epi,
-                                       hipStream_t stream) {
-    if (gemm_use_f32()) return launch_gemm(M, N, K, kb_count, batch, splitk, la, lb, epi, stream);
+                                       hipStream_t stream, bool exact = false) {
+    if (exact || gemm_use_f32()) return launch_gemm(M, N, K, kb_count, batch, splitk, la, lb, epi, stream);
     if (M <= 0 || N <= 0 || batch <= 0) return ARFE_OK;
     GemmDims d;
     d.M = M; d.N = N; d.K = K; d.kb_count = kb_count < 1 ? 1 : kb_count;

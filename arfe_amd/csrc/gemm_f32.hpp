@@ -35,23 +35,34 @@ struct GemmDims {
 // `kfast` tells the kernel which index is contiguous in memory so that consecutive lanes read consecutive
 // addresses.
 
+// Besides the scalar operator() (used by the exact-fp32 kernel) every loader offers the octet interface of the
+// bf16x3 kernel: `Row row(z, i)` caches what depends only on the row, `load8(row, z, kb, k0, v)` fetches 8 consecutive k.
+__device__ __forceinline__ void zero8(float (&v)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+}
+__device__ __forceinline__ void ld8_contig(const float* q, float (&v)[8]) {
+    const float4_u a = *reinterpret_cast<const float4_u*>(q);
+    const float4_u b = *reinterpret_cast<const float4_u*>(q + 4);
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+    v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+}
+
 struct LoadRowMajorK {   // element(i, k) = p[z*sz + kb*skb + i*ld + k]     (k contiguous)
     const float* p; int64_t sz, skb; int64_t ld; int rows, K;
     static constexpr bool kfast = true;
     __device__ __forceinline__ float operator()(int z, int kb, int i, int k) const {
         return (i < rows && k < K) ? p[z * sz + kb * skb + (int64_t)i * ld + k] : 0.f;
     }
-    // 8 consecutive k of one row: two 16-byte loads when the octet is inside the matrix
-    __device__ __forceinline__ void load8(int z, int kb, int i, int k0, float (&v)[8]) const {
-        if (i < rows && k0 + 7 < K) {
-            const float* q = p + z * sz + kb * skb + (int64_t)i * ld + k0;
-            const float4_u a = *reinterpret_cast<const float4_u*>(q);
-            const float4_u b = *reinterpret_cast<const float4_u*>(q + 4);
-            v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
-            v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
-        } else {
+    struct Row { const float* q; bool ok; };
+    __device__ __forceinline__ Row row(int z, int i) const { return Row{p + z * sz + (int64_t)i * ld, i < rows}; }
+    __device__ __forceinline__ void load8(const Row& r, int, int kb, int k0, float (&v)[8]) const {
+        if (!r.ok) { zero8(v); return; }
+        const float* q = r.q + kb * skb + k0;
+        if (k0 + 7 < K) ld8_contig(q, v);
+        else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (*this)(z, kb, i, k0 + j);
+            for (int j = 0; j < 8; ++j) v[j] = k0 + j < K ? q[j] : 0.f;
         }
     }
 };
@@ -60,6 +71,14 @@ struct LoadRowMajorI {   // element(i, k) = p[z*sz + kb*skb + k*ld + i]     (i c
     static constexpr bool kfast = false;
     __device__ __forceinline__ float operator()(int z, int kb, int i, int k) const {
         return (i < rows && k < K) ? p[z * sz + kb * skb + (int64_t)k * ld + i] : 0.f;
+    }
+    struct Row { const float* q; bool ok; };
+    __device__ __forceinline__ Row row(int z, int i) const { return Row{p + z * sz + i, i < rows}; }
+    __device__ __forceinline__ void load8(const Row& r, int, int kb, int k0, float (&v)[8]) const {
+        if (!r.ok) { zero8(v); return; }
+        const float* q = r.q + kb * skb + (int64_t)k0 * ld;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = k0 + j < K ? q[(int64_t)j * ld] : 0.f;
     }
 };
 

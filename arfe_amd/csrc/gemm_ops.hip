@@ -17,6 +17,27 @@ struct LoadMaskedK {   // element(i,k) = p[i*ld + k] * [mask[i*ld+k] > 0]
         if (mask && !(mask[o] > 0.f)) v = 0.f;
         return v;
     }
+    struct Row { int64_t o; bool ok; };
+    __device__ __forceinline__ Row row(int, int i) const { return Row{(int64_t)i * ld, i < rows}; }
+    __device__ __forceinline__ void load8(const Row& r, int, int, int k0, float (&v)[8]) const {
+        if (!r.ok) { zero8(v); return; }
+        if (k0 + 7 < K) {
+            ld8_contig(p + r.o + k0, v);
+            if (mask) {
+                float m[8];
+                ld8_contig(mask + r.o + k0, m);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (!(m[j] > 0.f)) v[j] = 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float t = 0.f;
+                if (k0 + j < K) { t = p[r.o + k0 + j]; if (mask && !(mask[r.o + k0 + j] > 0.f)) t = 0.f; }
+                v[j] = t;
+            }
+        }
+    }
 };
 struct LoadMaskedI {   // element(i,k) = p[k*ld + i] * [mask > 0]
     const float* p; const float* mask; int64_t ld; int rows, K;
@@ -27,6 +48,21 @@ struct LoadMaskedI {   // element(i,k) = p[k*ld + i] * [mask > 0]
         float v = p[o];
         if (mask && !(mask[o] > 0.f)) v = 0.f;
         return v;
+    }
+    struct Row { int i; bool ok; };
+    __device__ __forceinline__ Row row(int, int i) const { return Row{i, i < rows}; }
+    __device__ __forceinline__ void load8(const Row& r, int, int, int k0, float (&v)[8]) const {
+        if (!r.ok) { zero8(v); return; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float t = 0.f;
+            if (k0 + j < K) {
+                const int64_t o = (int64_t)(k0 + j) * ld + r.i;
+                t = p[o];
+                if (mask && !(mask[o] > 0.f)) t = 0.f;
+            }
+            v[j] = t;
+        }
     }
 };
 
@@ -44,6 +80,30 @@ struct ConvGatherB {   // B(n=(r,p), k=ci) for tap kb: x[r*roi_stride + ci*49 + 
         float v = x[(int64_t)r * roi_stride + q];
         if (mask && !(mask[(int64_t)r * mask_roi_stride + q] > 0.f)) v = 0.f;
         return v;
+    }
+    struct Row { const float* xb; const float* mb; int py, px; bool ok; };
+    __device__ __forceinline__ Row row(int, int n) const {
+        Row r;
+        r.ok = n < N;
+        const int ri = n / 49, p = n - ri * 49;
+        r.py = p / 7; r.px = p - r.py * 7;
+        r.xb = x + (int64_t)ri * roi_stride;
+        r.mb = mask ? mask + (int64_t)ri * mask_roi_stride : nullptr;
+        return r;
+    }
+    __device__ __forceinline__ void load8(const Row& r, int, int kb, int k0, float (&v)[8]) const {
+        const int yy = r.py + kb / 3 - 1, xx = r.px + kb % 3 - 1;
+        if (!r.ok || (unsigned)yy >= 7u || (unsigned)xx >= 7u) { zero8(v); return; }
+        const int q0 = k0 * 49 + yy * 7 + xx;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float t = 0.f;
+            if (k0 + j < Cin) {
+                t = r.xb[q0 + j * 49];
+                if (r.mb && !(r.mb[q0 + j * 49] > 0.f)) t = 0.f;
+            }
+            v[j] = t;
+        }
     }
 };
 struct EpiConv {       // y[r*roi_stride + co*49 + p] = act(v + bias[co])
@@ -66,6 +126,25 @@ struct WgradA {        // A(m=co, k=(r,p)) = dy[r*roi_stride + co*49 + p] * [rel
         if (mask && !(mask[o] > 0.f)) v = 0.f;
         return v;
     }
+    struct Row { int m; bool ok; };
+    __device__ __forceinline__ Row row(int, int m) const { return Row{m, m < Cout}; }
+    __device__ __forceinline__ void load8(const Row& r, int z, int kb, int k0, float (&v)[8]) const {
+        if (!r.ok) { zero8(v); return; }
+        const int ri = k0 / 49, p0 = k0 - ri * 49;
+        if (p0 + 7 < 49 && k0 + 7 < K) {          // the octet stays inside one RoI: 8 contiguous floats
+            const int64_t o = (int64_t)ri * roi_stride + r.m * 49 + p0;
+            ld8_contig(dy + o, v);
+            if (mask) {
+                float m8[8];
+                ld8_contig(mask + o, m8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (!(m8[j] > 0.f)) v[j] = 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (*this)(z, kb, r.m, k0 + j);
+        }
+    }
 };
 struct WgradB {        // B(n=ci, k=(r,p)) for tap z: x[r*roi_stride + ci*49 + shift(p, tap)]
     const float* x; int64_t roi_stride; int Cin, K;
@@ -77,6 +156,27 @@ struct WgradB {        // B(n=ci, k=(r,p)) for tap z: x[r*roi_stride + ci*49 + s
         int yy = py + z / 3 - 1, xx = px + z % 3 - 1;
         if ((unsigned)yy >= 7u || (unsigned)xx >= 7u) return 0.f;
         return x[(int64_t)r * roi_stride + n * 49 + yy * 7 + xx];
+    }
+    struct Row { int n; bool ok; };
+    __device__ __forceinline__ Row row(int, int n) const { return Row{n, n < Cin}; }
+    __device__ __forceinline__ void load8(const Row& r, int z, int kb, int k0, float (&v)[8]) const {
+        if (!r.ok) { zero8(v); return; }
+        const int ri = k0 / 49, p0 = k0 - ri * 49;
+        const int dyo = z / 3 - 1, dxo = z % 3 - 1, off = dyo * 7 + dxo;
+        // inside one RoI and the shifted window [p0+off, p0+off+7] inside the channel's 49 floats:
+        // one contiguous read, then the per-pixel padding mask
+        if (p0 + 7 < 49 && k0 + 7 < K && p0 + off >= 0 && p0 + off + 7 < 49) {
+            ld8_contig(x + (int64_t)ri * roi_stride + r.n * 49 + p0 + off, v);
+            int py = p0 / 7, px = p0 - py * 7;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if ((unsigned)(py + dyo) >= 7u || (unsigned)(px + dxo) >= 7u) v[j] = 0.f;
+                if (++px == 7) { px = 0; ++py; }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (*this)(z, kb, r.n, k0 + j);
+        }
     }
 };
 
@@ -462,14 +562,17 @@ extern "C" int32_t arfe_nonlocal_fwd(int32_t B, int32_t C, int32_t L, const floa
         LoadRowMajorI lb{m, CL, 0, L, L, C};
         EpiPlain e = epi_plain(tpg, 3 * CL, L);
         e.bias_m = bcat;
-        rc = launch_gemm_auto(3 * C, L, C, 1, B, 1, la, lb, e, st);
+        // theta and phi enter the logits: exact fp32 (see the S product below); 1.65 GFLOP/img
+        rc = launch_gemm_auto(3 * C, L, C, 1, B, 1, la, lb, e, st, /*exact=*/true);
         if (rc) return rc;
     }
     {   // S[z][i][j] = sum_c theta[c][i] phi[c][j]
         LoadRowMajorI la{tpg, 3 * CL, 0, L, L, C};
         LoadRowMajorI lb{tpg + CL, 3 * CL, 0, L, L, C};
         EpiPlain e = epi_plain(P, LL, L);
-        rc = launch_gemm_auto(L, L, C, 1, B, 1, la, lb, e, st);
+        // the logits feed exp(): keep this one contraction on the exact-fp32 MFMA so that the softmax is
+        // fp32-accurate for any weight scale (bf16x3's ~1e-5 |theta||phi| error is amplified by peaky rows)
+        rc = launch_gemm_auto(L, L, C, 1, B, 1, la, lb, e, st, /*exact=*/true);
         if (rc) return rc;
     }
     hipLaunchKernelGGL(nl_softmax_rows_kernel, dim3(B * L), dim3(256), 0, st, P, L);

@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void roialign_fwd_kernel(RoiLevels L, int R, c
 // RoIs (of all sets) are binned per 16x16 feature tile; one workgroup owns (tile, 32 channels), walks its RoI
 // list and WRITES every element of dfeats exactly once (no memset, no atomics on the feature maps).
 constexpr int RT = 16;          // tile edge
-constexpr int RB_CC = 32;       // channels per workgroup
+constexpr int RB_CC = 16;       // channels per workgroup
 constexpr int RB_MAXSETS = 4;
 
 struct RoiSets {
@@ -232,11 +232,18 @@ __device__ __forceinline__ float axis_weight(float start, float bin, int grid, i
     return w;
 }
 
+// One workgroup = (16x16 feature tile, RB_CC channels).  RoIs of the tile's list are taken RB_NB at a time so
+// that the dependent global reads of a batch (list -> roi -> G) overlap, and the column contraction
+//   T[c][ph][x] = sum_pw wx[pw][x] G[c][ph][pw]
+// is done once per batch in LDS instead of once per pixel row; a pixel then needs sum_ph wy[ph][y] T[c][ph][x].
+constexpr int RB_NB = 4;
 __global__ __launch_bounds__(256) void roialign_bwd_tiles_kernel(RoiLevels L, RoiSets S, RoiTileTable T, int P, int sample_num,
                                                                  const float* __restrict__ gout, int64_t g_roi_stride,
                                                                  const int* __restrict__ offsets, const int* __restrict__ list) {
-    __shared__ __attribute__((aligned(16))) float G_s[RB_CC][7][8];
-    __shared__ float wy_s[RT][8], wx_s[RT][8];
+    __shared__ __attribute__((aligned(16))) float G_s[RB_NB][RB_CC][7][8];
+    __shared__ float T_s[RB_NB][RB_CC][7][RT];
+    __shared__ float wy_s[RB_NB][RT][8], wx_s[RB_NB][RT][8];
+    __shared__ float inv_s[RB_NB];
     int tile = blockIdx.x, lvl = 0;
     while (lvl + 1 < L.n && tile >= T.first[lvl + 1]) ++lvl;
     const int local = tile - T.first[lvl];
@@ -254,51 +261,66 @@ __global__ __launch_bounds__(256) void roialign_bwd_tiles_kernel(RoiLevels L, Ro
     for (int c = 0; c < RB_CC; ++c) acc[c] = 0.f;
 
     const int beg = offsets[tile], end = offsets[tile + 1];
-    for (int e = beg; e < end; ++e) {
-        const int id = list[e];
-        const int s = id / S.R, k = id - s * S.R;
-        const RoiGeom g = roi_geom(S.rois[s] + 5 * (int64_t)k, scale, P, sample_num);
-        __syncthreads();                       // previous iteration's LDS reads are done
-        if (tid < RT * 7) {
-            const int r = tid / 7, pb = tid - r * 7;
-            wy_s[r][pb] = axis_weight(g.y_start, g.bin_h, g.grid_h, pb, H, ty * RT + r);
-        } else if (tid >= 128 && tid < 128 + RT * 7) {
-            const int t = tid - 128, r = t / 7, pb = t - r * 7;
-            wx_s[r][pb] = axis_weight(g.x_start, g.bin_w, g.grid_w, pb, W, tx * RT + r);
+    for (int e0 = beg; e0 < end; e0 += RB_NB) {
+        const int nb = end - e0 < RB_NB ? end - e0 : RB_NB;
+        __syncthreads();                       // previous batch's LDS reads are done
+        // ---- A: 1-D weights of every (roi, tile row / column, bin) ----
+        for (int idx = tid; idx < nb * 2 * RT * 7; idx += 256) {
+            const int j = idx / (2 * RT * 7), t = idx - j * (2 * RT * 7);
+            const int id = list[e0 + j];
+            const int s = id / S.R, k = id - s * S.R;
+            const RoiGeom g = roi_geom(S.rois[s] + 5 * (int64_t)k, scale, P, sample_num);
+            if (t < RT * 7) {
+                const int r = t / 7, pb = t - r * 7;
+                wy_s[j][r][pb] = axis_weight(g.y_start, g.bin_h, g.grid_h, pb, H, ty * RT + r);
+                if (t == 0) inv_s[j] = 1.0f / (float)(g.grid_h * g.grid_w > 1 ? g.grid_h * g.grid_w : 1);
+            } else {
+                const int u = t - RT * 7, r = u / 7, pb = u - r * 7;
+                wx_s[j][r][pb] = axis_weight(g.x_start, g.bin_w, g.grid_w, pb, W, tx * RT + r);
+            }
         }
-        const float* gp = gout + (int64_t)k * g_roi_stride + ((int64_t)s * L.C + c0) * 49;
-        for (int i = tid; i < ncc * 49; i += 256) {
-            const int c = i / 49, q = i - c * 49;
-            G_s[c][q / 7][q % 7] = gp[i];
+        // ---- B: upstream gradients of the batch ----
+        for (int idx = tid; idx < nb * ncc * 49; idx += 256) {
+            const int j = idx / (ncc * 49), rem = idx - j * (ncc * 49);
+            const int c = rem / 49, q = rem - c * 49;
+            const int id = list[e0 + j];
+            const int s = id / S.R, k = id - s * S.R;
+            G_s[j][c][q / 7][q % 7] = gout[(int64_t)k * g_roi_stride + ((int64_t)s * L.C + c0) * 49 + rem];
         }
         __syncthreads();
-        float wy[7], wx[7];
-#pragma unroll
-        for (int t = 0; t < 7; ++t) { wy[t] = wy_s[py][t]; wx[t] = wx_s[px][t]; }
-        const float inv = 1.0f / (float)(g.grid_h * g.grid_w > 1 ? g.grid_h * g.grid_w : 1);
-        // bins whose weight is non-zero for any of this wave's 4 rows (wave-uniform skip)
-        unsigned mask = 0;
-#pragma unroll
-        for (int t = 0; t < 7; ++t) mask |= (__any(wy[t] != 0.f) ? 1u : 0u) << t;
-        if (mask == 0 || !__any(wx[0] != 0.f || wx[1] != 0.f || wx[2] != 0.f || wx[3] != 0.f || wx[4] != 0.f ||
-                                wx[5] != 0.f || wx[6] != 0.f))
-            continue;
-#pragma unroll
-        for (int t = 0; t < 7; ++t) wy[t] *= inv;
-#pragma unroll
-        for (int c = 0; c < RB_CC; ++c) {
-            if (c >= ncc) break;
-            float sum = 0.f;
-#pragma unroll
-            for (int ph = 0; ph < 7; ++ph) {
-                if (!(mask & (1u << ph))) continue;
-                const float4 g0 = *reinterpret_cast<const float4*>(&G_s[c][ph][0]);
-                const float4 g1 = *reinterpret_cast<const float4*>(&G_s[c][ph][4]);
-                const float t = wx[0] * g0.x + wx[1] * g0.y + wx[2] * g0.z + wx[3] * g0.w + wx[4] * g1.x +
+        // ---- C: column contraction ----
+        for (int idx = tid; idx < nb * ncc * 7 * RT; idx += 256) {
+            const int xx = idx & (RT - 1);
+            int rest = idx >> 4;                 // RT == 16
+            const int ph = rest % 7; rest /= 7;
+            const int c = rest % ncc, j = rest / ncc;
+            const float4 g0 = *reinterpret_cast<const float4*>(&G_s[j][c][ph][0]);
+            const float4 g1 = *reinterpret_cast<const float4*>(&G_s[j][c][ph][4]);
+            const float* wx = wx_s[j][xx];
+            T_s[j][c][ph][xx] = wx[0] * g0.x + wx[1] * g0.y + wx[2] * g0.z + wx[3] * g0.w + wx[4] * g1.x +
                                 wx[5] * g1.y + wx[6] * g1.z;
-                sum += wy[ph] * t;
+        }
+        __syncthreads();
+        // ---- D: row contraction into the pixel accumulators ----
+        for (int j = 0; j < nb; ++j) {
+            float wy[7];
+            const float inv = inv_s[j];
+            unsigned mask = 0;
+#pragma unroll
+            for (int t = 0; t < 7; ++t) {
+                wy[t] = wy_s[j][py][t] * inv;
+                mask |= (__any(wy[t] != 0.f) ? 1u : 0u) << t;
             }
-            acc[c] += sum;
+            if (mask == 0) continue;
+#pragma unroll
+            for (int c = 0; c < RB_CC; ++c) {
+                if (c >= ncc) break;
+                float sum = 0.f;
+#pragma unroll
+                for (int ph = 0; ph < 7; ++ph)
+                    if (mask & (1u << ph)) sum += wy[ph] * T_s[j][c][ph][px];
+                acc[c] += sum;
+            }
         }
     }
     if (y < H && x < W) {
