@@ -87,6 +87,7 @@ struct EpiPlain {   // C[z*sz + m*ld + n] ; optional bias per row (m) or per col
                     // optional residual add (same layout as C), beta (0: overwrite, 1: accumulate)
     float* c; int64_t sz, ld;
     const float* bias_m; const float* bias_n; const float* residual;
+    const float* mask;      // optional: result is zeroed where mask[o] <= 0 (ReLU backward of the consumer), non-atomic only
     int relu; int accumulate; int atomic;
     __device__ __forceinline__ void operator()(int z, int m, int n, float v, bool first_split) const {
         int64_t o = z * sz + (int64_t)m * ld + n;
@@ -98,6 +99,7 @@ struct EpiPlain {   // C[z*sz + m*ld + n] ; optional bias per row (m) or per col
         if (atomic) { unsafeAtomicAdd(c + o, v); return; }
         if (accumulate) v += c[o];
         if (relu) v = fmaxf(v, 0.f);
+        if (mask && !(mask[o] > 0.f)) v = 0.f;
         c[o] = v;
     }
 };

@@ -106,12 +106,13 @@ struct ConvGatherB {   // B(n=(r,p), k=ci) for tap kb: x[r*roi_stride + ci*49 + 
         }
     }
 };
-struct EpiConv {       // y[r*roi_stride + co*49 + p] = act(v + bias[co])
-    float* y; int64_t roi_stride; const float* bias; int relu;
+struct EpiConv {       // y[r*roi_stride + co*49 + p] = act(v + bias[co]) * [mask > 0]
+    float* y; int64_t roi_stride; const float* bias; int relu; const float* mask; int64_t mask_roi_stride;
     __device__ __forceinline__ void operator()(int, int m, int n, float v, bool) const {
         int r = n / 49, p = n - r * 49;
         if (bias) v += bias[m];
         if (relu) v = fmaxf(v, 0.f);
+        if (mask && !(mask[(int64_t)r * mask_roi_stride + m * 49 + p] > 0.f)) v = 0.f;
         y[(int64_t)r * roi_stride + m * 49 + p] = v;
     }
 };
@@ -343,9 +344,15 @@ __global__ void relu_inplace_kernel(float* __restrict__ x, int64_t n) {
     for (; i < n; i += stride) x[i] = fmaxf(x[i], 0.f);
 }
 
+__global__ void mask_inplace_kernel(float* __restrict__ x, const float* __restrict__ m, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) if (!(m[i] > 0.f)) x[i] = 0.f;
+}
+
 static inline EpiPlain epi_plain(float* c, int64_t sz, int64_t ld) {
     EpiPlain e;
-    e.c = c; e.sz = sz; e.ld = ld; e.bias_m = nullptr; e.bias_n = nullptr; e.residual = nullptr;
+    e.c = c; e.sz = sz; e.ld = ld; e.bias_m = nullptr; e.bias_n = nullptr; e.residual = nullptr; e.mask = nullptr;
     e.relu = 0; e.accumulate = 0; e.atomic = 0;
     return e;
 }
@@ -407,21 +414,18 @@ extern "C" int32_t arfe_linear_fwd(int32_t R, int32_t in_f, int32_t out_f, const
 }
 
 extern "C" int32_t arfe_linear_bwd(int32_t R, int32_t in_f, int32_t out_f, const float* x, const float* w,
-                                   const float* dy, const float* relu_out, float* dx, int32_t accumulate_dx,
-                                   float* dw, float* db, void* stream) {
+                                   const float* dy, float* dx, int32_t accumulate_dx, int32_t mask_dx_by_x, float* dw,
+                                   float* db, void* stream) {
     ARFE_CHECK_ARG(R >= 0 && in_f > 0 && out_f > 0, ARFE_ERR_ARG, "linear_bwd: bad shape");
     hipStream_t st = as_stream(stream);
     if (dw && hipMemsetAsync(dw, 0, sizeof(float) * (size_t)out_f * in_f, st) != hipSuccess) return ARFE_ERR_LAUNCH;
     if (db && hipMemsetAsync(db, 0, sizeof(float) * (size_t)out_f, st) != hipSuccess) return ARFE_ERR_LAUNCH;
-    if (R == 0) {
-        if (dx && !accumulate_dx) return ARFE_OK;
-        return ARFE_OK;
-    }
+    if (R == 0) return ARFE_OK;
     ARFE_CHECK_ARG(x && w && dy, ARFE_ERR_ARG, "linear_bwd: null pointer");
     int32_t rc;
     if (dx) {
-        // dx[R,in] = dy_eff[R,out] . w[out,in] : A = dy (k=out contiguous, masked), B(n=in,k=out) = w[k*in + n]
-        LoadMaskedK la{dy, relu_out, out_f, R, out_f};
+        // dx[R,in] = dy[R,out] . w[out,in] : A = dy (k=out contiguous), B(n=in,k=out) = w[k*in + n]
+        LoadRowMajorK la{dy, 0, 0, out_f, R, out_f};
         LoadRowMajorI lb{w, 0, 0, in_f, in_f, out_f};
         int splitk = pick_splitk(R, in_f, 1, cdiv(out_f, gemm_bk()));
         EpiPlain e = epi_plain(dx, 0, in_f);
@@ -431,13 +435,20 @@ extern "C" int32_t arfe_linear_bwd(int32_t R, int32_t in_f, int32_t out_f, const
             e.atomic = 1;
         } else {
             e.accumulate = accumulate_dx;
+            if (mask_dx_by_x) e.mask = x;
         }
         rc = launch_gemm_auto(R, in_f, out_f, 1, 1, splitk, la, lb, e, st);
         if (rc) return rc;
+        if (splitk > 1 && mask_dx_by_x) {
+            int64_t n = (int64_t)R * in_f;
+            hipLaunchKernelGGL(mask_inplace_kernel, dim3((unsigned)(n / 256 + 1 < 4096 ? n / 256 + 1 : 4096)), dim3(256), 0, st,
+                               dx, x, n);
+            ARFE_CHECK_LAUNCH();
+        }
     }
     if (dw) {
-        // dw[out,in] = dy_eff^T[out,R] . x[R,in] : A(m=out,k=r) = dy[k*out + m] (m contiguous), B(n=in,k=r) = x[k*in+n]
-        LoadMaskedI la{dy, relu_out, out_f, out_f, R};
+        // dw[out,in] = dy^T[out,R] . x[R,in] : A(m=out,k=r) = dy[k*out + m] (m contiguous), B(n=in,k=r) = x[k*in+n]
+        LoadRowMajorI la{dy, 0, 0, out_f, out_f, R};
         LoadRowMajorI lb{x, 0, 0, in_f, in_f, R};
         int splitk = pick_splitk(out_f, in_f, 1, cdiv(R, gemm_bk()));
         EpiPlain e = epi_plain(dw, 0, in_f);
@@ -448,7 +459,7 @@ extern "C" int32_t arfe_linear_bwd(int32_t R, int32_t in_f, int32_t out_f, const
     if (db) {
         int chunk = 64;
         dim3 grid(cdiv(out_f, 256), cdiv(R, chunk));
-        hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, st, dy, relu_out, db, R, out_f, chunk);
+        hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, st, dy, (const float*)nullptr, db, R, out_f, chunk);
         ARFE_CHECK_LAUNCH();
     }
     return ARFE_OK;
@@ -483,26 +494,26 @@ extern "C" int32_t arfe_conv3x3_fwd(int32_t R, int32_t C, const float* x, int64_
     const float* wp = (const float*)packed;
     LoadRowMajorK la{wp, 0, (int64_t)C * C, C, C, C};     // A(m=co,k=ci) for tap kb
     ConvGatherB lb{x, nullptr, x_roi_stride, 0, R * 49, C};
-    EpiConv e{y, y_roi_stride, b, relu};
+    EpiConv e{y, y_roi_stride, b, relu, nullptr, 0};
     return launch_gemm_auto(C, R * 49, C, 9, 1, 1, la, lb, e, as_stream(stream));
 }
 
 extern "C" int32_t arfe_conv3x3_bwd_data(int32_t R, int32_t C, const void* packed, const float* dy,
-                                         const float* relu_out, int64_t dy_roi_stride, float* dx,
-                                         int64_t dx_roi_stride, void* stream) {
+                                         int64_t dy_roi_stride, float* dx, int64_t dx_roi_stride,
+                                         const float* dx_mask, int64_t dx_mask_roi_stride, void* stream) {
     ARFE_CHECK_ARG(R >= 0 && C > 0, ARFE_ERR_ARG, "conv3x3_bwd_data: bad shape");
     if (R == 0) return ARFE_OK;
     ARFE_CHECK_ARG(packed && dy && dx, ARFE_ERR_ARG, "conv3x3_bwd_data: null pointer");
     const float* wd = (const float*)packed + (size_t)9 * C * C;
     LoadRowMajorK la{wd, 0, (int64_t)C * C, C, C, C};      // A(m=ci,k=co) = w[co][ci][8-tap]
-    ConvGatherB lb{dy, relu_out, dy_roi_stride, dy_roi_stride, R * 49, C};
-    EpiConv e{dx, dx_roi_stride, nullptr, 0};
+    ConvGatherB lb{dy, nullptr, dy_roi_stride, 0, R * 49, C};
+    EpiConv e{dx, dx_roi_stride, nullptr, 0, dx_mask, dx_mask_roi_stride};
     return launch_gemm_auto(C, R * 49, C, 9, 1, 1, la, lb, e, as_stream(stream));
 }
 
 extern "C" int32_t arfe_conv3x3_bwd_weight(int32_t R, int32_t C, const float* x, int64_t x_roi_stride,
-                                           const float* dy, const float* relu_out, int64_t dy_roi_stride,
-                                           float* dw, float* db, void* workspace, void* stream) {
+                                           const float* dy, int64_t dy_roi_stride, float* dw, float* db,
+                                           void* workspace, void* stream) {
     ARFE_CHECK_ARG(R >= 0 && C > 0 && dw && db, ARFE_ERR_ARG, "conv3x3_bwd_weight: bad arguments");
     hipStream_t st = as_stream(stream);
     if (hipMemsetAsync(db, 0, sizeof(float) * (size_t)C, st) != hipSuccess) return ARFE_ERR_LAUNCH;
@@ -514,7 +525,7 @@ extern "C" int32_t arfe_conv3x3_bwd_weight(int32_t R, int32_t C, const float* x,
     float* dwp = (float*)workspace;
     int total = 9 * C * C;
     if (hipMemsetAsync(dwp, 0, sizeof(float) * (size_t)total, st) != hipSuccess) return ARFE_ERR_LAUNCH;
-    WgradA la{dy, relu_out, dy_roi_stride, C, R * 49};
+    WgradA la{dy, nullptr, dy_roi_stride, C, R * 49};
     WgradB lb{x, x_roi_stride, C, R * 49};
     int ksteps = cdiv(R * 49, gemm_bk());
     int splitk = pick_splitk(C, C, 9, ksteps);
@@ -526,7 +537,7 @@ extern "C" int32_t arfe_conv3x3_bwd_weight(int32_t R, int32_t C, const float* x,
     ARFE_CHECK_LAUNCH();
     int chunk = 32;
     dim3 grid(C, cdiv(R, chunk));
-    hipLaunchKernelGGL(reduce_mid_kernel, grid, dim3(64), 0, st, dy, relu_out, db, R, dy_roi_stride, 49, chunk);
+    hipLaunchKernelGGL(reduce_mid_kernel, grid, dim3(64), 0, st, dy, (const float*)nullptr, db, R, dy_roi_stride, 49, chunk);
     ARFE_CHECK_LAUNCH();
     return ARFE_OK;
 }

@@ -237,10 +237,11 @@ __device__ __forceinline__ float axis_weight(float start, float bin, int grid, i
 //   T[c][ph][x] = sum_pw wx[pw][x] G[c][ph][pw]
 // is done once per batch in LDS instead of once per pixel row; a pixel then needs sum_ph wy[ph][y] T[c][ph][x].
 constexpr int RB_NB = 4;
+static_assert(RB_CC == 16 && RT == 16, "phase C maps the 16 lane-groups of a workgroup to the 16 channels of a chunk");
 __global__ __launch_bounds__(256) void roialign_bwd_tiles_kernel(RoiLevels L, RoiSets S, RoiTileTable T, int P, int sample_num,
                                                                  const float* __restrict__ gout, int64_t g_roi_stride,
                                                                  const int* __restrict__ offsets, const int* __restrict__ list) {
-    __shared__ __attribute__((aligned(16))) float G_s[RB_NB][RB_CC][7][8];
+    __shared__ float G_s[RB_NB][RB_CC][49];
     __shared__ float T_s[RB_NB][RB_CC][7][RT];
     __shared__ float wy_s[RB_NB][RT][8], wx_s[RB_NB][RT][8];
     __shared__ float inv_s[RB_NB];
@@ -261,44 +262,46 @@ __global__ __launch_bounds__(256) void roialign_bwd_tiles_kernel(RoiLevels L, Ro
     for (int c = 0; c < RB_CC; ++c) acc[c] = 0.f;
 
     const int beg = offsets[tile], end = offsets[tile + 1];
+    const int grp = tid >> 4;                  // phase C role: channel c0+grp, all 7 bin rows, column px
     for (int e0 = beg; e0 < end; e0 += RB_NB) {
         const int nb = end - e0 < RB_NB ? end - e0 : RB_NB;
         __syncthreads();                       // previous batch's LDS reads are done
-        // ---- A: 1-D weights of every (roi, tile row / column, bin) ----
-        for (int idx = tid; idx < nb * 2 * RT * 7; idx += 256) {
-            const int j = idx / (2 * RT * 7), t = idx - j * (2 * RT * 7);
+        for (int j = 0; j < nb; ++j) {
             const int id = list[e0 + j];
             const int s = id / S.R, k = id - s * S.R;
-            const RoiGeom g = roi_geom(S.rois[s] + 5 * (int64_t)k, scale, P, sample_num);
-            if (t < RT * 7) {
-                const int r = t / 7, pb = t - r * 7;
-                wy_s[j][r][pb] = axis_weight(g.y_start, g.bin_h, g.grid_h, pb, H, ty * RT + r);
-                if (t == 0) inv_s[j] = 1.0f / (float)(g.grid_h * g.grid_w > 1 ? g.grid_h * g.grid_w : 1);
-            } else {
-                const int u = t - RT * 7, r = u / 7, pb = u - r * 7;
-                wx_s[j][r][pb] = axis_weight(g.x_start, g.bin_w, g.grid_w, pb, W, tx * RT + r);
+            // ---- A: 1-D weights (threads 0..111: rows, 128..239: columns) ----
+            if (tid < RT * 7 || (tid >= 128 && tid < 128 + RT * 7)) {
+                const RoiGeom g = roi_geom(S.rois[s] + 5 * (int64_t)k, scale, P, sample_num);
+                if (tid < 128) {
+                    const int r = tid / 7, pb = tid - r * 7;
+                    wy_s[j][r][pb] = axis_weight(g.y_start, g.bin_h, g.grid_h, pb, H, ty * RT + r);
+                    if (tid == 0) inv_s[j] = 1.0f / (float)(g.grid_h * g.grid_w > 1 ? g.grid_h * g.grid_w : 1);
+                } else {
+                    const int u = tid - 128, r = u / 7, pb = u - r * 7;
+                    wx_s[j][r][pb] = axis_weight(g.x_start, g.bin_w, g.grid_w, pb, W, tx * RT + r);
+                }
             }
-        }
-        // ---- B: upstream gradients of the batch ----
-        for (int idx = tid; idx < nb * ncc * 49; idx += 256) {
-            const int j = idx / (ncc * 49), rem = idx - j * (ncc * 49);
-            const int c = rem / 49, q = rem - c * 49;
-            const int id = list[e0 + j];
-            const int s = id / S.R, k = id - s * S.R;
-            G_s[j][c][q / 7][q % 7] = gout[(int64_t)k * g_roi_stride + ((int64_t)s * L.C + c0) * 49 + rem];
+            // ---- B: upstream gradients: ncc*49 contiguous floats, straight copy ----
+            const float* gp = gout + (int64_t)k * g_roi_stride + ((int64_t)s * L.C + c0) * 49;
+            float* gs = &G_s[j][0][0];
+            for (int i = tid; i < ncc * 49; i += 256) gs[i] = gp[i];
         }
         __syncthreads();
-        // ---- C: column contraction ----
-        for (int idx = tid; idx < nb * ncc * 7 * RT; idx += 256) {
-            const int xx = idx & (RT - 1);
-            int rest = idx >> 4;                 // RT == 16
-            const int ph = rest % 7; rest /= 7;
-            const int c = rest % ncc, j = rest / ncc;
-            const float4 g0 = *reinterpret_cast<const float4*>(&G_s[j][c][ph][0]);
-            const float4 g1 = *reinterpret_cast<const float4*>(&G_s[j][c][ph][4]);
-            const float* wx = wx_s[j][xx];
-            T_s[j][c][ph][xx] = wx[0] * g0.x + wx[1] * g0.y + wx[2] * g0.z + wx[3] * g0.w + wx[4] * g1.x +
-                                wx[5] * g1.y + wx[6] * g1.z;
+        // ---- C: column contraction T[c][ph][x] = sum_pw wx[x][pw] G[c][ph][pw] ----
+        if (grp < ncc) {
+            for (int j = 0; j < nb; ++j) {
+                float wx[7];
+#pragma unroll
+                for (int t = 0; t < 7; ++t) wx[t] = wx_s[j][px][t];
+                const float* gs = &G_s[j][grp][0];
+#pragma unroll
+                for (int ph = 0; ph < 7; ++ph) {
+                    float t = 0.f;
+#pragma unroll
+                    for (int pw = 0; pw < 7; ++pw) t += wx[pw] * gs[ph * 7 + pw];
+                    T_s[j][grp][ph][px] = t;
+                }
+            }
         }
         __syncthreads();
         // ---- D: row contraction into the pixel accumulators ----
@@ -314,7 +317,6 @@ __global__ __launch_bounds__(256) void roialign_bwd_tiles_kernel(RoiLevels L, Ro
             if (mask == 0) continue;
 #pragma unroll
             for (int c = 0; c < RB_CC; ++c) {
-                if (c >= ncc) break;
                 float sum = 0.f;
 #pragma unroll
                 for (int ph = 0; ph < 7; ++ph)
@@ -346,15 +348,19 @@ __global__ void rff_fuse_fwd_kernel(int64_t total, int per_roi, const float* __r
 }
 __global__ void rff_fuse_bwd_kernel(int64_t total, int per_roi, const float* __restrict__ ori, int64_t ori_roi_stride,
                                     const float* __restrict__ lw, const float* __restrict__ lh, const float* __restrict__ dz,
-                                    float* __restrict__ d_ori, int64_t d_ori_roi_stride, float* __restrict__ dl) {
+                                    float* __restrict__ d_ori, int64_t d_ori_roi_stride, float* __restrict__ dlw,
+                                    float* __restrict__ dlh) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int64_t r = i / per_roi;
     const int q = (int)(i - r * per_roi);
     const float o = ori[r * ori_roi_stride + q];
     const float g = dz[i];
-    d_ori[r * d_ori_roi_stride + q] = g + g * (lw[i] + lh[i]);
-    dl[i] = g * o;
+    const float a = lw[i], b = lh[i];
+    d_ori[r * d_ori_roi_stride + q] = g + g * (a + b);
+    const float go = g * o;
+    dlw[i] = a > 0.f ? go : 0.f;       // ReLU of wh_conv / hh_conv folded in (lw, lh are post-ReLU)
+    dlh[i] = b > 0.f ? go : 0.f;
 }
 
 static int32_t fill_roi_levels(RoiLevels& L, const arfe_pyramid_t* pyr, const float* const* feats, float* const* dfeats,
@@ -505,14 +511,14 @@ extern "C" int32_t arfe_rff_fuse_fwd(int32_t R, int32_t C, const float* ori, int
 }
 
 extern "C" int32_t arfe_rff_fuse_bwd(int32_t R, int32_t C, const float* ori, int64_t ori_roi_stride, const float* lw,
-                                     const float* lh, const float* dz, float* d_ori, int64_t d_ori_roi_stride, float* dl,
-                                     void* stream) {
+                                     const float* lh, const float* dz, float* d_ori, int64_t d_ori_roi_stride, float* dlw,
+                                     float* dlh, void* stream) {
     ARFE_CHECK_ARG(R >= 0 && C > 0, ARFE_ERR_ARG, "rff_fuse_bwd: bad shape");
     if (R == 0) return ARFE_OK;
-    ARFE_CHECK_ARG(ori && lw && lh && dz && d_ori && dl, ARFE_ERR_ARG, "rff_fuse_bwd: null pointer");
+    ARFE_CHECK_ARG(ori && lw && lh && dz && d_ori && dlw && dlh, ARFE_ERR_ARG, "rff_fuse_bwd: null pointer");
     const int64_t total = (int64_t)R * C * 49;
     hipLaunchKernelGGL(rff_fuse_bwd_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, as_stream(stream), total,
-                       C * 49, ori, ori_roi_stride, lw, lh, dz, d_ori, d_ori_roi_stride, dl);
+                       C * 49, ori, ori_roi_stride, lw, lh, dz, d_ori, d_ori_roi_stride, dlw, dlh);
     ARFE_CHECK_LAUNCH();
     return ARFE_OK;
 }

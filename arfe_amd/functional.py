@@ -336,14 +336,16 @@ def conv3x3_fwd_op(x_view, roi_stride, R, C, packed, b, relu):
     return y
 
 
-def conv3x3_bwd_op(x_view, x_roi_stride, R, C, w, packed, dy, relu_out, dx_view, dx_roi_stride, ws):
+def conv3x3_bwd_op(x_view, x_roi_stride, R, C, w, packed, dy, dx_view, dx_roi_stride, ws, dx_mask=0, dx_mask_stride=0):
+    """dy must already carry this conv's ReLU backward; dx is masked by dx_mask (the ReLU that fed this conv)."""
     dw = torch.empty_like(w)
     db = torch.empty(C, device=w.device)
     with probe('conv3x3_bwd_data'):
-        check(hip.lib().arfe_conv3x3_bwd_data(R, C, ptr(packed), ptr(dy), ptr(relu_out), C * 49, dx_view, dx_roi_stride,
-                                              stream()), "arfe_conv3x3_bwd_data")
-    check(hip.lib().arfe_conv3x3_bwd_weight(R, C, x_view, x_roi_stride, ptr(dy), ptr(relu_out), C * 49, ptr(dw), ptr(db),
-                                            ptr(ws), stream()), "arfe_conv3x3_bwd_weight")
+        check(hip.lib().arfe_conv3x3_bwd_data(R, C, ptr(packed), ptr(dy), C * 49, dx_view, dx_roi_stride, dx_mask,
+                                              dx_mask_stride, stream()), "arfe_conv3x3_bwd_data")
+    with probe('conv3x3_bwd_weight'):
+        check(hip.lib().arfe_conv3x3_bwd_weight(R, C, x_view, x_roi_stride, ptr(dy), C * 49, ptr(dw), ptr(db), ptr(ws),
+                                                stream()), "arfe_conv3x3_bwd_weight")
     return dw, db
 
 
@@ -355,14 +357,16 @@ def linear_fwd_op(x, w, b, relu):
     return y
 
 
-def linear_bwd_op(x, w, dy, relu_out, dx=None, accumulate_dx=False, need_dx=True):
+def linear_bwd_op(x, w, dy, dx=None, accumulate_dx=False, mask_dx_by_x=False, need_dx=True):
+    """dy is used as is (ReLU backward is applied by the producer of dy: mask_dx_by_x of the later layer)."""
     R, out_f, in_f = x.shape[0], w.shape[0], w.shape[1]
     if need_dx and dx is None:
         dx = torch.empty(R, in_f, device=x.device)
     dw = torch.empty_like(w)
     db = torch.empty(out_f, device=x.device)
-    check(hip.lib().arfe_linear_bwd(R, in_f, out_f, ptr(x), ptr(w), ptr(dy), ptr(relu_out), ptr(dx) if need_dx else 0,
-                                    int(accumulate_dx), ptr(dw), ptr(db), stream()), "arfe_linear_bwd")
+    check(hip.lib().arfe_linear_bwd(R, in_f, out_f, ptr(x), ptr(w), ptr(dy), ptr(dx) if need_dx else 0,
+                                    int(accumulate_dx), int(mask_dx_by_x), ptr(dw), ptr(db), stream()),
+          "arfe_linear_bwd")
     return dx, dw, db
 
 
@@ -404,18 +408,21 @@ class RFFHeadFunction(torch.autograd.Function):
         dcls = dcls.contiguous() if dcls is not None else torch.zeros(R, wc.shape[0], device=dev)
         dreg = dreg.contiguous() if dreg is not None else torch.zeros(R, wr.shape[0], device=dev)
         ws = _ws(hip.lib().arfe_conv3x3_workspace_bytes(C), dev)
-        df2, dwc, dbc = linear_bwd_op(f2, wc, dcls, None)
-        _, dwr, dbr = linear_bwd_op(f2, wr, dreg, None, dx=df2, accumulate_dx=True)
-        df1, dw2, db2 = linear_bwd_op(f1, w2, df2, f2)
-        dz2, dw1, db1 = linear_bwd_op(z2.view(R, -1), w1, df1, f1)
+        # every ReLU backward is folded into the epilogue of the kernel that PRODUCES the gradient
+        df2, dwc, dbc = linear_bwd_op(f2, wc, dcls)
+        _, dwr, dbr = linear_bwd_op(f2, wr, dreg, dx=df2, accumulate_dx=True, mask_dx_by_x=True)   # df2 *= [f2>0]
+        df1, dw2, db2 = linear_bwd_op(f1, w2, df2, mask_dx_by_x=True)                             # df1 *= [f1>0]
+        z2f = z2.view(R, -1)
+        dz2, dw1, db1 = linear_bwd_op(z2f, w1, df1, mask_dx_by_x=True)                            # dz2 *= [z2>0]
         dz = torch.empty(R, C, 7, 7, device=dev)
-        dwf, dbf = conv3x3_bwd_op(z.data_ptr(), C * 49, R, C, w_f, pk_f, dz2, z2, dz.data_ptr(), C * 49, ws)
+        dwf, dbf = conv3x3_bwd_op(z.data_ptr(), C * 49, R, C, w_f, pk_f, dz2, dz.data_ptr(), C * 49, ws)
         dx = torch.empty_like(x)
-        dl = torch.empty(R, C, 7, 7, device=dev)
-        check(hip.lib().arfe_rff_fuse_bwd(R, C, x.data_ptr(), rs, ptr(lw), ptr(lh), ptr(dz), dx.data_ptr(), rs, ptr(dl),
-                                          stream()), "arfe_rff_fuse_bwd")
-        dwwh, dbwh = conv3x3_bwd_op(x.data_ptr() + 4 * C * 49, rs, R, C, w_wh, pk_wh, dl, lw, dx.data_ptr() + 4 * C * 49, rs, ws)
-        dwhh, dbhh = conv3x3_bwd_op(x.data_ptr() + 8 * C * 49, rs, R, C, w_hh, pk_hh, dl, lh, dx.data_ptr() + 8 * C * 49, rs, ws)
+        dlw = torch.empty(R, C, 7, 7, device=dev)
+        dlh = torch.empty(R, C, 7, 7, device=dev)
+        check(hip.lib().arfe_rff_fuse_bwd(R, C, x.data_ptr(), rs, ptr(lw), ptr(lh), ptr(dz), dx.data_ptr(), rs, ptr(dlw),
+                                          ptr(dlh), stream()), "arfe_rff_fuse_bwd")
+        dwwh, dbwh = conv3x3_bwd_op(x.data_ptr() + 4 * C * 49, rs, R, C, w_wh, pk_wh, dlw, dx.data_ptr() + 4 * C * 49, rs, ws)
+        dwhh, dbhh = conv3x3_bwd_op(x.data_ptr() + 8 * C * 49, rs, R, C, w_hh, pk_hh, dlh, dx.data_ptr() + 8 * C * 49, rs, ws)
         return dx, dwwh, dbwh, dwhh, dbhh, dwf, dbf, dw1, db1, dw2, db2, dwc, dbc, dwr, dbr
 
 

@@ -157,33 +157,35 @@ int32_t arfe_conv3x3_pack_weights(int32_t C, const float* w, void* packed, void*
 /* y = act(conv(x; w) + b) */
 int32_t arfe_conv3x3_fwd(int32_t R, int32_t C, const float* x, int64_t x_roi_stride, const void* packed,
                          const float* b, int32_t relu, float* y, int64_t y_roi_stride, void* stream);
-/* dy_eff = relu_out ? dy * [relu_out > 0] : dy (relu_out = the forward output, shares dy's addressing).
- * dx = conv^T(dy_eff) */
-int32_t arfe_conv3x3_bwd_data(int32_t R, int32_t C, const void* packed, const float* dy, const float* relu_out,
-                              int64_t dy_roi_stride, float* dx, int64_t dx_roi_stride, void* stream);
-/* dw = x (*) dy_eff  [C,C,3,3], db = sum dy_eff  [C] */
+/* ReLU backward is folded into the PRODUCER of each gradient (epilogue masks), so dy is used as is.
+ * dx = conv^T(dy) * [dx_mask > 0]   (dx_mask optional: the post-ReLU tensor that fed this conv's input, addressed
+ * like dx with its own roi stride) */
+int32_t arfe_conv3x3_bwd_data(int32_t R, int32_t C, const void* packed, const float* dy, int64_t dy_roi_stride,
+                              float* dx, int64_t dx_roi_stride, const float* dx_mask, int64_t dx_mask_roi_stride,
+                              void* stream);
+/* dw = x (*) dy  [C,C,3,3], db = sum dy  [C] */
 int32_t arfe_conv3x3_bwd_weight(int32_t R, int32_t C, const float* x, int64_t x_roi_stride, const float* dy,
-                                const float* relu_out, int64_t dy_roi_stride, float* dw, float* db,
-                                void* workspace, void* stream);
+                                int64_t dy_roi_stride, float* dw, float* db, void* workspace, void* stream);
 
 /* fusion (multirois_bbox_head.py:175-182): z = ori + ori * (lw + lh); ori is a slice (roi stride given),
  * lw, lh, z are dense [R,C,7,7]. */
 int32_t arfe_rff_fuse_fwd(int32_t R, int32_t C, const float* ori, int64_t ori_roi_stride, const float* lw,
                           const float* lh, float* z, void* stream);
-/* d_ori = dz (1 + lw + lh) ; dlw = dz * ori ; dlh = dz * ori  (the ReLU masks of lw/lh are applied by
- * arfe_conv3x3_bwd through relu_out).  d_ori is written with d_ori_roi_stride; dlw == dlh is written once. */
+/* d_ori = dz (1 + lw + lh) ; dlw = dz * ori * [lw > 0] ; dlh = dz * ori * [lh > 0]  (lw, lh are the post-ReLU conv
+ * outputs, so the ReLU backward of wh_conv / hh_conv is applied here).  d_ori is written with d_ori_roi_stride. */
 int32_t arfe_rff_fuse_bwd(int32_t R, int32_t C, const float* ori, int64_t ori_roi_stride, const float* lw,
                           const float* lh, const float* dz, float* d_ori, int64_t d_ori_roi_stride,
-                          float* dl, void* stream);
+                          float* dlw, float* dlh, void* stream);
 
 /* nn.Linear (shared_fcs / fc_cls / fc_reg, multirois_bbox_head.py:203-235): y = act(x W^T + b),
  * x [R,in], W [out,in], y [R,out]. */
 int32_t arfe_linear_fwd(int32_t R, int32_t in_f, int32_t out_f, const float* x, const float* w, const float* b,
                         int32_t relu, float* y, void* stream);
-/* dy_eff = relu_out ? dy*[relu_out>0] : dy; dx = dy_eff W (written, or accumulated when accumulate_dx != 0;
- * dx may be NULL), dw = dy_eff^T x, db = colsum(dy_eff). */
+/* dx = (dy W) (* [x > 0] when mask_dx_by_x: x is then the post-ReLU output of the previous layer, so the mask is
+ * that layer's ReLU backward); written, or accumulated when accumulate_dx != 0; dx may be NULL.
+ * dw = dy^T x, db = colsum(dy). */
 int32_t arfe_linear_bwd(int32_t R, int32_t in_f, int32_t out_f, const float* x, const float* w,
-                        const float* dy, const float* relu_out, float* dx, int32_t accumulate_dx, float* dw,
+                        const float* dy, float* dx, int32_t accumulate_dx, int32_t mask_dx_by_x, float* dw,
                         float* db, void* stream);
 
 #ifdef __cplusplus
