@@ -83,11 +83,27 @@ struct Levels {
     int r;        // refine level
     int B, C;
     int H[ARFE_MAX_LEVELS], W[ARFE_MAX_LEVELS];
+    // log2 of the exact power-of-two size ratio to the refine level in BOTH dimensions:
+    //   sh > 0: level is finer  (H = Hr << sh)   sh < 0: coarser (Hr = H << -sh)   sh == 0: same size
+    //   SH_GENERAL: no such ratio -> kernels take the generic index path (ragged / unpadded pyramids)
+    int sh[ARFE_MAX_LEVELS];
 };
+constexpr int SH_GENERAL = 99;
+static inline int pow2_shift(int big, int small) {   // big == small << s ? s : -1
+    for (int s = 0; s < 16; ++s) if ((small << s) == big) return s;
+    return -1;
+}
 static inline Levels to_levels(const arfe_pyramid_t* p) {
     Levels l;
     l.n = p->num_levels; l.r = p->refine_level; l.B = p->batch; l.C = p->channels;
-    for (int i = 0; i < ARFE_MAX_LEVELS; ++i) { l.H[i] = p->height[i]; l.W[i] = p->width[i]; }
+    for (int i = 0; i < ARFE_MAX_LEVELS; ++i) { l.H[i] = p->height[i]; l.W[i] = p->width[i]; l.sh[i] = SH_GENERAL; }
+    const int hr = p->height[l.r], wr = p->width[l.r];
+    for (int i = 0; i < l.n; ++i) {
+        int a = pow2_shift(l.H[i], hr), b = pow2_shift(l.W[i], wr);
+        if (a >= 0 && a == b) { l.sh[i] = a; continue; }
+        a = pow2_shift(hr, l.H[i]); b = pow2_shift(wr, l.W[i]);
+        if (a >= 0 && a == b) l.sh[i] = -a;
+    }
     return l;
 }
 int32_t check_pyramid(const arfe_pyramid_t* p);

@@ -303,9 +303,19 @@ __global__ __launch_bounds__(256) void fpn_scatter_bwd_dbsf_kernel(Levels lv, Le
     float acc = 0.f;
     for (int i = 0; i < lv.n; ++i) {
         const int h = lv.H[i], w = lv.W[i];
-        const float ys = nearest_scale(hr, h), xs = nearest_scale(wr, w);
-        const int y0 = nearest_dst_begin(sy, hr, h, ys), y1 = nearest_dst_begin(sy + 1, hr, h, ys);
-        const int x0 = nearest_dst_begin(sx, wr, w, xs), x1 = nearest_dst_begin(sx + 1, wr, w, xs);
+        int y0, y1, x0, x1;
+        const int sh = lv.sh[i];
+        if (sh != SH_GENERAL && sh >= 0) {            // finer or equal level: dst block [s<<sh, (s+1)<<sh)
+            y0 = sy << sh; y1 = (sy + 1) << sh; x0 = sx << sh; x1 = (sx + 1) << sh;
+        } else if (sh != SH_GENERAL) {                // coarser level: dst d reads src d << -sh
+            const int f = -sh, m = (1 << f) - 1;
+            if ((sy & m) || (sx & m)) continue;
+            y0 = sy >> f; y1 = y0 + 1; x0 = sx >> f; x1 = x0 + 1;
+        } else {
+            const float ys = nearest_scale(hr, h), xs = nearest_scale(wr, w);
+            y0 = nearest_dst_begin(sy, hr, h, ys); y1 = nearest_dst_begin(sy + 1, hr, h, ys);
+            x0 = nearest_dst_begin(sx, wr, w, xs); x1 = nearest_dst_begin(sx + 1, wr, w, xs);
+        }
         const float* gp = gout.p[i] + bc * (int64_t)h * w;
         const float* ap = a.p[i] + (int64_t)bi * h * w;
         const float* bp = b.p[i] + (int64_t)bi * h * w;
@@ -388,39 +398,60 @@ __global__ __launch_bounds__(256) void fpn_input_bwd_kernel(Levels lv, QuadTable
         }
     }
     // gather^T
-    const float inv_n = (float)lv.n;
+    const float nlev = (float)lv.n;
     const int64_t plane_r = (int64_t)hr * wr;
     const float* dmp = dm + bc * plane_r;
+    const int sh = lv.sh[lvl];
     if (lvl < lv.r) {
         const int32_t* am = argmax + (int64_t)lvl * lv.B * lv.C * plane_r + bc * plane_r;
-        int oy0 = (int)(((int64_t)y * hr) / h) - 1;
+        if (sh != SH_GENERAL && sh >= 0) {          // windows are the disjoint (1<<sh)^2 blocks: exactly one candidate
+            const int oy = y >> sh;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int xx = x0 + e;
+                if (xx >= w) break;
+                const int64_t o = (int64_t)oy * wr + (xx >> sh);
+                if (am[o] == y * w + xx) r[e] += dmp[o] / nlev;
+            }
+        } else {
+            const int oy0 = (int)(((int64_t)y * hr) / h) - 1;
+            for (int e = 0; e < 4; ++e) {
+                const int xx = x0 + e;
+                if (xx >= w) break;
+                const int ox0 = (int)(((int64_t)xx * wr) / w) - 1;
+                const int flat = y * w + xx;
+                for (int oy = oy0; oy <= oy0 + 2; ++oy) {
+                    if (oy < 0 || oy >= hr) continue;
+                    if (y < pool_start(oy, h, hr) || y >= pool_end(oy, h, hr)) continue;
+                    for (int ox = ox0; ox <= ox0 + 2; ++ox) {
+                        if (ox < 0 || ox >= wr) continue;
+                        if (xx < pool_start(ox, w, wr) || xx >= pool_end(ox, w, wr)) continue;
+                        if (am[(int64_t)oy * wr + ox] == flat) r[e] += dmp[(int64_t)oy * wr + ox] / nlev;
+                    }
+                }
+            }
+        }
+    } else if (sh != SH_GENERAL) {                   // coarser (or same) level: refine block [y<<f, (y+1)<<f)
+        const int f = -sh, n = 1 << f;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int xx = x0 + e;
             if (xx >= w) break;
-            const int ox0 = (int)(((int64_t)xx * wr) / w) - 1;
-            const int flat = y * w + xx;
-            for (int oy = oy0; oy <= oy0 + 2; ++oy) {
-                if (oy < 0 || oy >= hr) continue;
-                if (y < pool_start(oy, h, hr) || y >= pool_end(oy, h, hr)) continue;
-                for (int ox = ox0; ox <= ox0 + 2; ++ox) {
-                    if (ox < 0 || ox >= wr) continue;
-                    if (xx < pool_start(ox, w, wr) || xx >= pool_end(ox, w, wr)) continue;
-                    if (am[(int64_t)oy * wr + ox] == flat) r[e] += dmp[(int64_t)oy * wr + ox] / inv_n;
-                }
-            }
+            float s = 0.f;
+            for (int py = y << f; py < (y << f) + n; ++py)
+                for (int px = xx << f; px < (xx << f) + n; ++px) s += dmp[(int64_t)py * wr + px] / nlev;
+            r[e] += s;
         }
     } else {
         const float ys = nearest_scale(h, hr), xs = nearest_scale(w, wr);
         const int py0 = nearest_dst_begin(y, h, hr, ys), py1 = nearest_dst_begin(y + 1, h, hr, ys);
-#pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int xx = x0 + e;
             if (xx >= w) break;
             const int px0 = nearest_dst_begin(xx, w, wr, xs), px1 = nearest_dst_begin(xx + 1, w, wr, xs);
             float s = 0.f;
             for (int py = py0; py < py1; ++py)
-                for (int px = px0; px < px1; ++px) s += dmp[(int64_t)py * wr + px] / inv_n;
+                for (int px = px0; px < px1; ++px) s += dmp[(int64_t)py * wr + px] / nlev;
             r[e] += s;
         }
     }
@@ -435,61 +466,83 @@ __global__ __launch_bounds__(256) void fpn_input_bwd_kernel(Levels lv, QuadTable
 
 // =========================================================================================================
 // gate-conv weight gradients: dw[c,ky,kx] = sum_{b,y,x} x[c, y+ky-1, x+kx-1] * dpre[y,x]
-//   block = (row chunk, channel, level*B + b); each thread walks pixels of the chunk, 18 accumulators.
+//   one workgroup per (channel, level) walks every image plane in pixel quads: 5 row reads of x (16 B + 2 halo
+//   scalars each, the row above/below come from L1/L2) and two 16-B map reads feed 72 FMAs; the 18 (+2 bias)
+//   accumulators are reduced once per workgroup, so results are written without atomics.
 // =========================================================================================================
-constexpr int WG_ROWS = 8;
-__global__ __launch_bounds__(256) void fpn_gate_wgrad_kernel(Levels lv, int lvl, const float* __restrict__ x,
-                                                             const float* __restrict__ dpa, const float* __restrict__ dpb,
-                                                             float* __restrict__ dw1, float* __restrict__ db1,
-                                                             float* __restrict__ dw2, float* __restrict__ db2) {
-    const int h = lv.H[lvl], w = lv.W[lvl];
-    const int c = blockIdx.y, bi = blockIdx.z;
-    const int y_begin = blockIdx.x * WG_ROWS;
-    const int y_end = y_begin + WG_ROWS < h ? y_begin + WG_ROWS : h;
-    // input rows that touch output rows [y_begin, y_end): [y_begin-1, y_end+1) clipped; to count every product
-    // exactly once the block owns the x rows [y_begin, y_end) and pairs them with dpre rows yy-(ky-1).
-    const float* xp = x + ((int64_t)bi * lv.C + c) * h * w;
-    const float* da = dpa + (int64_t)bi * h * w;
-    const float* db = dpb + (int64_t)bi * h * w;
+__global__ __launch_bounds__(256) void fpn_gate_wgrad_kernel(Levels lv, LevelPtrs x, LevelPtrs dpa, LevelPtrs dpb,
+                                                             LevelMutPtrs dw1, LevelMutPtrs db1, LevelMutPtrs dw2,
+                                                             LevelMutPtrs db2) {
+    const int c = blockIdx.x, lvl = blockIdx.y;
+    const int h = lv.H[lvl], w = lv.W[lvl], wq = (w + 3) >> 2;
     float s1[9], s2[9], sa = 0.f, sb = 0.f;
 #pragma unroll
     for (int t = 0; t < 9; ++t) { s1[t] = 0.f; s2[t] = 0.f; }
-    const int npx = (y_end - y_begin) * w;
-    for (int i = threadIdx.x; i < npx; i += 256) {
-        const int yy = y_begin + i / w, xx = i % w;
-        const float xv = xp[(int64_t)yy * w + xx];
+    const int nq = h * wq;
+    for (int bi = 0; bi < lv.B; ++bi) {
+        const float* xp = x.p[lvl] + ((int64_t)bi * lv.C + c) * h * w;
+        const float* da = dpa.p[lvl] + (int64_t)bi * h * w;
+        const float* db = dpb.p[lvl] + (int64_t)bi * h * w;
+        for (int q = threadIdx.x; q < nq; q += 256) {
+            const int y = q / wq, x0 = (q - y * wq) << 2;
+            float a4[4], b4[4];
+            if (x0 + 3 < w) {
+                const float4_u av = *reinterpret_cast<const float4_u*>(da + (int64_t)y * w + x0);
+                const float4_u bv = *reinterpret_cast<const float4_u*>(db + (int64_t)y * w + x0);
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int oy = yy - (ky - 1);
-            if (oy < 0 || oy >= h) continue;
+                for (int e = 0; e < 4; ++e) { a4[e] = av[e]; b4[e] = bv[e]; }
+            } else {
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int ox = xx - (kx - 1);
-                if (ox < 0 || ox >= w) continue;
-                s1[ky * 3 + kx] += xv * da[(int64_t)oy * w + ox];
-                s2[ky * 3 + kx] += xv * db[(int64_t)oy * w + ox];
+                for (int e = 0; e < 4; ++e) {
+                    const bool ok = x0 + e < w;
+                    a4[e] = ok ? da[(int64_t)y * w + x0 + e] : 0.f;
+                    b4[e] = ok ? db[(int64_t)y * w + x0 + e] : 0.f;
+                }
+            }
+            if (c == 0) { sa += (a4[0] + a4[1]) + (a4[2] + a4[3]); sb += (b4[0] + b4[1]) + (b4[2] + b4[3]); }
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int yy = y + ky - 1;
+                if (yy < 0 || yy >= h) continue;
+                const float* row = xp + (int64_t)yy * w;
+                float v[6];
+                v[0] = x0 > 0 ? row[x0 - 1] : 0.f;
+                if (x0 + 4 < w) {
+                    const float4_u m = *reinterpret_cast<const float4_u*>(row + x0);
+                    v[1] = m[0]; v[2] = m[1]; v[3] = m[2]; v[4] = m[3];
+                    v[5] = row[x0 + 4];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 5; ++e) v[1 + e] = x0 + e < w ? row[x0 + e] : 0.f;
+                }
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        s1[ky * 3 + kx] += v[e + kx] * a4[e];
+                        s2[ky * 3 + kx] += v[e + kx] * b4[e];
+                    }
             }
         }
-        if (c == 0) { sa += da[(int64_t)yy * w + xx]; sb += db[(int64_t)yy * w + xx]; }
     }
     __shared__ float red[4][20];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-        float v1 = wave_sum(s1[t]), v2 = wave_sum(s2[t]);
+        const float v1 = wave_sum(s1[t]), v2 = wave_sum(s2[t]);
         if (lane == 0) { red[wv][t] = v1; red[wv][9 + t] = v2; }
     }
     {
-        float v1 = wave_sum(sa), v2 = wave_sum(sb);
+        const float v1 = wave_sum(sa), v2 = wave_sum(sb);
         if (lane == 0) { red[wv][18] = v1; red[wv][19] = v2; }
     }
     __syncthreads();
     if (threadIdx.x < 20) {
         const int t = threadIdx.x;
         const float v = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
-        if (t < 9) unsafeAtomicAdd(dw1 + c * 9 + t, v);
-        else if (t < 18) unsafeAtomicAdd(dw2 + c * 9 + (t - 9), v);
-        else if (c == 0) unsafeAtomicAdd(t == 18 ? db1 : db2, v);
+        if (t < 9) dw1.p[lvl][c * 9 + t] = v;
+        else if (t < 18) dw2.p[lvl][c * 9 + (t - 9)] = v;
+        else if (c == 0) (t == 18 ? db1.p[lvl] : db2.p[lvl])[0] = v;
     }
 }
 
@@ -667,22 +720,14 @@ extern "C" int32_t arfe_fpn_gate_wgrad(const arfe_pyramid_t* pyr, const float* c
     int32_t rc = check_pyramid(pyr);
     if (rc) return rc;
     Levels lv = to_levels(pyr);
-    hipStream_t st = as_stream(stream);
-    ARFE_CHECK_ARG(x && dpre_a && dpre_b && dw1 && db1 && dw2 && db2, ARFE_ERR_ARG, "fpn_gate_wgrad: null pointer");
-    for (int i = 0; i < lv.n; ++i) {
-        ARFE_CHECK_ARG(x[i] && dpre_a[i] && dpre_b[i] && dw1[i] && db1[i] && dw2[i] && db2[i], ARFE_ERR_ARG,
-                       "fpn_gate_wgrad: null pointer at level %d", i);
-        if (hipMemsetAsync(dw1[i], 0, sizeof(float) * 9 * lv.C, st) != hipSuccess ||
-            hipMemsetAsync(dw2[i], 0, sizeof(float) * 9 * lv.C, st) != hipSuccess ||
-            hipMemsetAsync(db1[i], 0, sizeof(float), st) != hipSuccess ||
-            hipMemsetAsync(db2[i], 0, sizeof(float), st) != hipSuccess) {
-            set_error("fpn_gate_wgrad: memset failed");
-            return ARFE_ERR_LAUNCH;
-        }
-        dim3 grid(cdiv(lv.H[i], WG_ROWS), lv.C, lv.B);
-        hipLaunchKernelGGL(fpn_gate_wgrad_kernel, grid, dim3(256), 0, st, lv, i, x[i], dpre_a[i], dpre_b[i], dw1[i], db1[i],
-                           dw2[i], db2[i]);
-        ARFE_CHECK_LAUNCH();
-    }
+    LevelPtrs xp, dap, dbp;
+    LevelMutPtrs w1p, b1p, w2p, b2p;
+    ARFE_CHECK_ARG(fill_ptrs(xp, x, lv.n) && fill_ptrs(dap, dpre_a, lv.n) && fill_ptrs(dbp, dpre_b, lv.n) &&
+                       fill_ptrs(w1p, dw1, lv.n) && fill_ptrs(b1p, db1, lv.n) && fill_ptrs(w2p, dw2, lv.n) &&
+                       fill_ptrs(b2p, db2, lv.n),
+                   ARFE_ERR_ARG, "fpn_gate_wgrad: null pointer");
+    hipLaunchKernelGGL(fpn_gate_wgrad_kernel, dim3(lv.C, lv.n), dim3(256), 0, as_stream(stream), lv, xp, dap, dbp, w1p, b1p,
+                       w2p, b2p);
+    ARFE_CHECK_LAUNCH();
     return ARFE_OK;
 }
