@@ -232,20 +232,63 @@ __device__ __forceinline__ float axis_weight(float start, float bin, int grid, i
     return w;
 }
 
+// Per-RoI 1-D bilinear weight tables (one small workgroup per RoI, all sets): for the RoI's first RW_EXT feature
+// rows / columns, w[axis][bin][i] = sum over the bin's grid samples of the tap weight on feature index origin+i.
+// The tile kernel then only copies its 16-row / 16-column slice instead of re-deriving the geometry per tile.
+constexpr int RW_EXT = 64;
+struct RoiWeightHdr { int y0, x0, big; float inv; };     // origin of the table, big: extent > RW_EXT (tile computes)
+
+__global__ __launch_bounds__(256) void roi_weight_table_kernel(RoiLevels L, RoiSets S, int P, int sample_num,
+                                                               RoiWeightHdr* __restrict__ hdr, float* __restrict__ wtab) {
+    const int id = blockIdx.x;
+    const int s = id / S.R, k = id - s * S.R;
+    int lvl = (int)S.levels[s][k];
+    lvl = lvl < 0 ? 0 : (lvl >= L.n ? L.n - 1 : lvl);
+    const int H = L.H[lvl], W = L.W[lvl];
+    const RoiGeom g = roi_geom(S.rois[s] + 5 * (int64_t)k, L.scale[lvl], P, sample_num);
+    int y0 = 0, y1 = -1, x0 = 0, x1 = -1;
+    const bool oky = axis_range(g.y_start, g.bin_h * (float)P, H, y0, y1);
+    const bool okx = axis_range(g.x_start, g.bin_w * (float)P, W, x0, x1);
+    const int big = (oky && okx && (y1 - y0 >= RW_EXT - 1 || x1 - x0 >= RW_EXT - 1)) ? 1 : 0;
+    if (threadIdx.x == 0) {
+        RoiWeightHdr h;
+        h.y0 = y0; h.x0 = x0; h.big = big;
+        h.inv = 1.0f / (float)(g.grid_h * g.grid_w > 1 ? g.grid_h * g.grid_w : 1);
+        hdr[id] = h;
+    }
+    if (big || !oky || !okx) return;
+    float* wt = wtab + (int64_t)id * 2 * 7 * RW_EXT;
+    for (int i = threadIdx.x; i < 2 * 7 * RW_EXT; i += 256) {
+        const int axis = i / (7 * RW_EXT), rem = i - axis * 7 * RW_EXT;
+        const int pb = rem / RW_EXT, off = rem - pb * RW_EXT;
+        wt[i] = axis == 0 ? axis_weight(g.y_start, g.bin_h, g.grid_h, pb, H, y0 + off)
+                          : axis_weight(g.x_start, g.bin_w, g.grid_w, pb, W, x0 + off);
+    }
+}
+
 // One workgroup = (16x16 feature tile, RB_CC channels).  RoIs of the tile's list are taken RB_NB at a time so
 // that the dependent global reads of a batch (list -> roi -> G) overlap, and the column contraction
 //   T[c][ph][x] = sum_pw wx[pw][x] G[c][ph][pw]
 // is done once per batch in LDS instead of once per pixel row; a pixel then needs sum_ph wy[ph][y] T[c][ph][x].
 constexpr int RB_NB = 4;
+constexpr int RB_SEGS = 4;        // slices of a long RoI list
+constexpr int RB_SEG_MIN = 32;    // lists up to this length stay in one workgroup (plain stores)
 static_assert(RB_CC == 16 && RT == 16, "phase C maps the 16 lane-groups of a workgroup to the 16 channels of a chunk");
 __global__ __launch_bounds__(256) void roialign_bwd_tiles_kernel(RoiLevels L, RoiSets S, RoiTileTable T, int P, int sample_num,
                                                                  const float* __restrict__ gout, int64_t g_roi_stride,
-                                                                 const int* __restrict__ offsets, const int* __restrict__ list) {
-    __shared__ float G_s[RB_NB][RB_CC][49];
-    __shared__ float T_s[RB_NB][RB_CC][7][RT];
-    __shared__ float wy_s[RB_NB][RT][8], wx_s[RB_NB][RT][8];
-    __shared__ float inv_s[RB_NB];
-    int tile = blockIdx.x, lvl = 0;
+                                                                 const int* __restrict__ offsets, const int* __restrict__ list,
+                                                                 const RoiWeightHdr* __restrict__ hdr,
+                                                                 const float* __restrict__ wtab) {
+    __shared__ __attribute__((aligned(16))) float G_s[RB_NB][RB_CC][7][8];       // [roi][c][ph][pw (+1 pad)]
+    __shared__ __attribute__((aligned(16))) float T_s[RB_NB][7][RB_CC / 4][RT][4];  // [roi][ph][c/4][x][c%4]
+    __shared__ __attribute__((aligned(16))) float wy_s[RB_NB][RT][8], wx_s[RB_NB][RT][8];
+    // coarse levels hold few tiles with long RoI lists: dispatch them first (reverse tile order) and cut a long
+    // list into RB_SEGS slices handled by different workgroups (those add atomically into the zeroed output)
+    int tile = (int)gridDim.x - 1 - (int)blockIdx.x, lvl = 0;
+    const int lbeg = offsets[tile], lend = offsets[tile + 1];
+    const int nseg = (lend - lbeg) > RB_SEG_MIN ? RB_SEGS : 1;
+    const int seg = blockIdx.z;
+    if (seg >= nseg) return;
     while (lvl + 1 < L.n && tile >= T.first[lvl + 1]) ++lvl;
     const int local = tile - T.first[lvl];
     const int tx = local % T.tiles_x[lvl];
@@ -261,7 +304,9 @@ __global__ __launch_bounds__(256) void roialign_bwd_tiles_kernel(RoiLevels L, Ro
 #pragma unroll
     for (int c = 0; c < RB_CC; ++c) acc[c] = 0.f;
 
-    const int beg = offsets[tile], end = offsets[tile + 1];
+    const int per_seg = (lend - lbeg + nseg - 1) / nseg;
+    const int beg = lbeg + seg * per_seg;
+    const int end = beg + per_seg < lend ? beg + per_seg : lend;
     const int grp = tid >> 4;                  // phase C role: channel c0+grp, all 7 bin rows, column px
     for (int e0 = beg; e0 < end; e0 += RB_NB) {
         const int nb = end - e0 < RB_NB ? end - e0 : RB_NB;
@@ -269,59 +314,64 @@ __global__ __launch_bounds__(256) void roialign_bwd_tiles_kernel(RoiLevels L, Ro
         for (int j = 0; j < nb; ++j) {
             const int id = list[e0 + j];
             const int s = id / S.R, k = id - s * S.R;
-            // ---- A: 1-D weights (threads 0..111: rows, 128..239: columns) ----
+            // ---- A: this tile's slice of the RoI's 1-D weight tables (threads 0..111 rows, 128..239 columns) ----
             if (tid < RT * 7 || (tid >= 128 && tid < 128 + RT * 7)) {
-                const RoiGeom g = roi_geom(S.rois[s] + 5 * (int64_t)k, scale, P, sample_num);
-                if (tid < 128) {
-                    const int r = tid / 7, pb = tid - r * 7;
-                    wy_s[j][r][pb] = axis_weight(g.y_start, g.bin_h, g.grid_h, pb, H, ty * RT + r);
-                    if (tid == 0) inv_s[j] = 1.0f / (float)(g.grid_h * g.grid_w > 1 ? g.grid_h * g.grid_w : 1);
+                const RoiWeightHdr h = hdr[id];
+                const int axis = tid >> 7, u = tid & 127, r = u / 7, pb = u - r * 7;
+                float w;
+                if (!h.big) {
+                    const int off = (axis ? tx * RT - h.x0 : ty * RT - h.y0) + r;
+                    w = (off >= 0 && off < RW_EXT) ? wtab[((int64_t)id * 2 + axis) * 7 * RW_EXT + pb * RW_EXT + off] : 0.f;
                 } else {
-                    const int u = tid - 128, r = u / 7, pb = u - r * 7;
-                    wx_s[j][r][pb] = axis_weight(g.x_start, g.bin_w, g.grid_w, pb, W, tx * RT + r);
+                    const RoiGeom g = roi_geom(S.rois[s] + 5 * (int64_t)k, scale, P, sample_num);
+                    w = axis ? axis_weight(g.x_start, g.bin_w, g.grid_w, pb, W, tx * RT + r)
+                             : axis_weight(g.y_start, g.bin_h, g.grid_h, pb, H, ty * RT + r);
                 }
+                if (axis) wx_s[j][r][pb] = w; else wy_s[j][r][pb] = w * h.inv;
             }
-            // ---- B: upstream gradients: ncc*49 contiguous floats, straight copy ----
+            // ---- B: upstream gradients: ncc*49 contiguous floats ----
             const float* gp = gout + (int64_t)k * g_roi_stride + ((int64_t)s * L.C + c0) * 49;
-            float* gs = &G_s[j][0][0];
-            for (int i = tid; i < ncc * 49; i += 256) gs[i] = gp[i];
+            for (int i = tid; i < ncc * 49; i += 256) {
+                const int c = i / 49, q = i - c * 49, ph = q / 7;
+                G_s[j][c][ph][q - ph * 7] = gp[i];
+            }
         }
         __syncthreads();
-        // ---- C: column contraction T[c][ph][x] = sum_pw wx[x][pw] G[c][ph][pw] ----
+        // ---- C: column contraction T[ph][x][c] = sum_pw wx[x][pw] G[c][ph][pw] ----
         if (grp < ncc) {
             for (int j = 0; j < nb; ++j) {
-                float wx[7];
-#pragma unroll
-                for (int t = 0; t < 7; ++t) wx[t] = wx_s[j][px][t];
-                const float* gs = &G_s[j][grp][0];
+                const float4 w0 = *reinterpret_cast<const float4*>(&wx_s[j][px][0]);
+                const float4 w1 = *reinterpret_cast<const float4*>(&wx_s[j][px][4]);
 #pragma unroll
                 for (int ph = 0; ph < 7; ++ph) {
-                    float t = 0.f;
-#pragma unroll
-                    for (int pw = 0; pw < 7; ++pw) t += wx[pw] * gs[ph * 7 + pw];
-                    T_s[j][grp][ph][px] = t;
+                    const float4 g0 = *reinterpret_cast<const float4*>(&G_s[j][grp][ph][0]);
+                    const float4 g1 = *reinterpret_cast<const float4*>(&G_s[j][grp][ph][4]);
+                    T_s[j][ph][grp >> 2][px][grp & 3] = w0.x * g0.x + w0.y * g0.y + w0.z * g0.z + w0.w * g0.w + w1.x * g1.x +
+                                          w1.y * g1.y + w1.z * g1.z;
                 }
             }
         }
         __syncthreads();
-        // ---- D: row contraction into the pixel accumulators ----
+        // ---- D: row contraction into the pixel accumulators (4 channels per LDS read) ----
         for (int j = 0; j < nb; ++j) {
-            float wy[7];
-            const float inv = inv_s[j];
+            const float4 y0v = *reinterpret_cast<const float4*>(&wy_s[j][py][0]);
+            const float4 y1v = *reinterpret_cast<const float4*>(&wy_s[j][py][4]);
+            const float wy[7] = {y0v.x, y0v.y, y0v.z, y0v.w, y1v.x, y1v.y, y1v.z};
             unsigned mask = 0;
 #pragma unroll
-            for (int t = 0; t < 7; ++t) {
-                wy[t] = wy_s[j][py][t] * inv;
-                mask |= (__any(wy[t] != 0.f) ? 1u : 0u) << t;
-            }
+            for (int t = 0; t < 7; ++t) mask |= (__any(wy[t] != 0.f) ? 1u : 0u) << t;
             if (mask == 0) continue;
 #pragma unroll
-            for (int c = 0; c < RB_CC; ++c) {
-                float sum = 0.f;
+            for (int ph = 0; ph < 7; ++ph) {
+                if (!(mask & (1u << ph))) continue;
 #pragma unroll
-                for (int ph = 0; ph < 7; ++ph)
-                    if (mask & (1u << ph)) sum += wy[ph] * T_s[j][c][ph][px];
-                acc[c] += sum;
+                for (int c4 = 0; c4 < RB_CC / 4; ++c4) {
+                    const float4 t = *reinterpret_cast<const float4*>(&T_s[j][ph][c4][px][0]);
+                    acc[4 * c4 + 0] += wy[ph] * t.x;
+                    acc[4 * c4 + 1] += wy[ph] * t.y;
+                    acc[4 * c4 + 2] += wy[ph] * t.z;
+                    acc[4 * c4 + 3] += wy[ph] * t.w;
+                }
             }
         }
     }
@@ -330,9 +380,15 @@ __global__ __launch_bounds__(256) void roialign_bwd_tiles_kernel(RoiLevels L, Ro
 #pragma unroll
         for (int i = 1; i < ARFE_MAX_LEVELS; ++i) if (i == lvl) d = L.dfeat[i];
         d += (((int64_t)b * L.C + c0) * H + y) * W + x;
+        if (nseg == 1) {
 #pragma unroll
-        for (int c = 0; c < RB_CC; ++c)
-            if (c < ncc) d[(int64_t)c * H * W] = acc[c];
+            for (int c = 0; c < RB_CC; ++c)
+                if (c < ncc) d[(int64_t)c * H * W] = acc[c];
+        } else {
+#pragma unroll
+            for (int c = 0; c < RB_CC; ++c)
+                if (c < ncc) unsafeAtomicAdd(d + (int64_t)c * H * W, acc[c]);
+        }
     }
 }
 
@@ -445,8 +501,9 @@ extern "C" int64_t arfe_roialign_bwd_workspace_bytes(const arfe_pyramid_t* pyr, 
     if (check_pyramid(pyr) || nsets < 1 || nsets > RB_MAXSETS || R < 0) return -1;
     int ntiles, mx;
     make_roi_tile_table(pyr, &ntiles, &mx);
-    // counts[ntiles] | offsets[ntiles+1] | cursors[ntiles] | list[nsets*R*mx]
-    return ((int64_t)3 * ntiles + 1 + (int64_t)nsets * R * mx + 16) * (int64_t)sizeof(int);
+    // counts[ntiles] | offsets[ntiles+1] | cursors[ntiles] | list[nsets*R*mx] | hdr[nsets*R] | wtab[nsets*R][2][7][RW_EXT]
+    return ((int64_t)3 * ntiles + 1 + (int64_t)nsets * R * mx + 16) * (int64_t)sizeof(int) +
+           (int64_t)nsets * R * ((int64_t)sizeof(RoiWeightHdr) + (int64_t)2 * 7 * RW_EXT * sizeof(float)) + 64;
 }
 
 extern "C" int32_t arfe_roialign_bwd(const arfe_pyramid_t* pyr, float* const* dfeats, const int32_t* strides,
@@ -474,6 +531,11 @@ extern "C" int32_t arfe_roialign_bwd(const arfe_pyramid_t* pyr, float* const* df
     int* offsets = counts + ntiles;
     int* cursors = offsets + ntiles + 1;
     int* list = cursors + ntiles;
+    const int nroi_all = nsets * R;
+    uintptr_t after = (uintptr_t)(list + (size_t)nroi_all * mx);
+    after = (after + 15) & ~(uintptr_t)15;
+    RoiWeightHdr* hdr = (RoiWeightHdr*)after;
+    float* wtab = (float*)(hdr + nroi_all);
     hipStream_t st = as_stream(stream);
     if (hipMemsetAsync(counts, 0, sizeof(int) * (size_t)ntiles, st) != hipSuccess) {
         set_error("roialign_bwd: memset failed");
@@ -492,8 +554,18 @@ extern "C" int32_t arfe_roialign_bwd(const arfe_pyramid_t* pyr, float* const* df
                            (const int*)offsets, cursors, list);
         ARFE_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(roialign_bwd_tiles_kernel, dim3(ntiles, cdiv(L.C, RB_CC)), dim3(256), 0, st, L, S, T, pooled,
-                       sample_num, gout, gout_roi_stride, (const int*)offsets, (const int*)list);
+    for (int i = 0; i < L.n; ++i)      // tiles whose list is cut into slices accumulate atomically
+        if (hipMemsetAsync(L.dfeat[i], 0, sizeof(float) * (size_t)L.B * L.C * L.H[i] * L.W[i], st) != hipSuccess) {
+            set_error("roialign_bwd: memset failed");
+            return ARFE_ERR_LAUNCH;
+        }
+    if (nroi > 0) {
+        hipLaunchKernelGGL(roi_weight_table_kernel, dim3(nroi), dim3(256), 0, st, L, S, pooled, sample_num, hdr, wtab);
+        ARFE_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(roialign_bwd_tiles_kernel, dim3(ntiles, cdiv(L.C, RB_CC), RB_SEGS), dim3(256), 0, st, L, S, T, pooled,
+                       sample_num, gout, gout_roi_stride, (const int*)offsets, (const int*)list,
+                       (const RoiWeightHdr*)hdr, (const float*)wtab);
     ARFE_CHECK_LAUNCH();
     return ARFE_OK;
 }
