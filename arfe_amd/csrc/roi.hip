@@ -93,43 +93,6 @@ __device__ __forceinline__ bool axis_tap(float c, int n, int& lo, int& hi, float
     return true;
 }
 
-// one thread per (roi, channel, bin), bins fastest -> coalesced output
-__global__ __launch_bounds__(256) void roialign_fwd_kernel(RoiLevels L, int R, const float* __restrict__ rois,
-                                                           const int64_t* __restrict__ levels, int P, int sample_num,
-                                                           float* __restrict__ out, int64_t out_roi_stride) {
-    const int64_t total = (int64_t)R * L.C * P * P;
-    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    const int pw = (int)(idx % P), ph = (int)((idx / P) % P);
-    const int c = (int)((idx / (P * P)) % L.C);
-    const int k = (int)(idx / ((int64_t)P * P * L.C));
-    int lvl = (int)levels[k];
-    lvl = lvl < 0 ? 0 : (lvl >= L.n ? L.n - 1 : lvl);
-    int H = L.H[0], W = L.W[0];
-    float scale = L.scale[0];
-    const float* feat = L.feat[0];
-#pragma unroll
-    for (int i = 1; i < ARFE_MAX_LEVELS; ++i)
-        if (i == lvl) { H = L.H[i]; W = L.W[i]; scale = L.scale[i]; feat = L.feat[i]; }
-    const RoiGeom g = roi_geom(rois + 5 * (int64_t)k, scale, P, sample_num);
-    const float* f = feat + ((int64_t)g.batch * L.C + c) * H * W;
-    float acc = 0.f;
-    for (int iy = 0; iy < g.grid_h; ++iy) {
-        const float y = g.y_start + ph * g.bin_h + ((float)iy + 0.5f) * g.bin_h / (float)g.grid_h;
-        int y0, y1; float wy0, wy1;
-        const bool oky = axis_tap(y, H, y0, y1, wy0, wy1);
-        for (int ix = 0; ix < g.grid_w; ++ix) {
-            const float x = g.x_start + pw * g.bin_w + ((float)ix + 0.5f) * g.bin_w / (float)g.grid_w;
-            int x0, x1; float wx0, wx1;
-            const bool okx = axis_tap(x, W, x0, x1, wx0, wx1);
-            if (!(oky && okx)) continue;
-            acc += wy0 * wx0 * f[y0 * W + x0] + wy0 * wx1 * f[y0 * W + x1] + wy1 * wx0 * f[y1 * W + x0] +
-                   wy1 * wx1 * f[y1 * W + x1];
-        }
-    }
-    out[(int64_t)k * out_roi_stride + (int64_t)c * P * P + ph * P + pw] = acc / g.count;
-}
-
 // ---- RoIAlign backward without atomics ------------------------------------------------------------------------
 // The scatter form (one thread per output bin, 4 atomics per sample) moves ~5 GB of dword atomics per step and
 // ran at 9 ms per RoI set.  The bilinear sample weights are separable (w = wy(row) * wx(col)), so the gradient
@@ -236,10 +199,17 @@ __device__ __forceinline__ float axis_weight(float start, float bin, int grid, i
 // rows / columns, w[axis][bin][i] = sum over the bin's grid samples of the tap weight on feature index origin+i.
 // The tile kernel then only copies its 16-row / 16-column slice instead of re-deriving the geometry per tile.
 constexpr int RW_EXT = 64;
-struct RoiWeightHdr { int y0, x0, big; float inv; };     // origin of the table, big: extent > RW_EXT (tile computes)
+// big: 0 table valid, 1 window larger than the table (consumers compute on the fly), 2 no sample inside the map
+struct RoiWeightHdr {
+    int y0, x0, big; float inv;
+    int hext, wext;                 // rows / columns of the window that carry weight
+    int ylo[7], yhi[7];             // row support [ylo, yhi) of bin ph (offsets into the table)
+    int xlo[7], xhi[7];             // column support of bin pw
+};
 
 __global__ __launch_bounds__(256) void roi_weight_table_kernel(RoiLevels L, RoiSets S, int P, int sample_num,
                                                                RoiWeightHdr* __restrict__ hdr, float* __restrict__ wtab) {
+    __shared__ float w_s[2][7][RW_EXT];
     const int id = blockIdx.x;
     const int s = id / S.R, k = id - s * S.R;
     int lvl = (int)S.levels[s][k];
@@ -249,20 +219,142 @@ __global__ __launch_bounds__(256) void roi_weight_table_kernel(RoiLevels L, RoiS
     int y0 = 0, y1 = -1, x0 = 0, x1 = -1;
     const bool oky = axis_range(g.y_start, g.bin_h * (float)P, H, y0, y1);
     const bool okx = axis_range(g.x_start, g.bin_w * (float)P, W, x0, x1);
-    const int big = (oky && okx && (y1 - y0 >= RW_EXT - 1 || x1 - x0 >= RW_EXT - 1)) ? 1 : 0;
+    const int big = !(oky && okx) ? 2 : ((y1 - y0 >= RW_EXT - 1 || x1 - x0 >= RW_EXT - 1) ? 1 : 0);
+    RoiWeightHdr* h = hdr + id;
     if (threadIdx.x == 0) {
-        RoiWeightHdr h;
-        h.y0 = y0; h.x0 = x0; h.big = big;
-        h.inv = 1.0f / (float)(g.grid_h * g.grid_w > 1 ? g.grid_h * g.grid_w : 1);
-        hdr[id] = h;
+        h->y0 = y0; h->x0 = x0; h->big = big;
+        h->inv = 1.0f / (float)(g.grid_h * g.grid_w > 1 ? g.grid_h * g.grid_w : 1);
     }
-    if (big || !oky || !okx) return;
+    if (big) return;
     float* wt = wtab + (int64_t)id * 2 * 7 * RW_EXT;
     for (int i = threadIdx.x; i < 2 * 7 * RW_EXT; i += 256) {
         const int axis = i / (7 * RW_EXT), rem = i - axis * 7 * RW_EXT;
         const int pb = rem / RW_EXT, off = rem - pb * RW_EXT;
-        wt[i] = axis == 0 ? axis_weight(g.y_start, g.bin_h, g.grid_h, pb, H, y0 + off)
-                          : axis_weight(g.x_start, g.bin_w, g.grid_w, pb, W, x0 + off);
+        float w = axis == 0 ? axis_weight(g.y_start, g.bin_h, g.grid_h, pb, H, y0 + off)
+                            : axis_weight(g.x_start, g.bin_w, g.grid_w, pb, W, x0 + off);
+        if ((axis == 0 ? y0 : x0) + off >= (axis == 0 ? H : W)) w = 0.f;
+        wt[i] = w;
+        (&w_s[0][0][0])[i] = w;
+    }
+    __syncthreads();
+    if (threadIdx.x < 14) {            // support of each bin along each axis
+        const int axis = threadIdx.x / 7, pb = threadIdx.x - axis * 7;
+        int lo = 0, hi = 0;
+        bool any = false;
+        for (int i = 0; i < RW_EXT; ++i)
+            if (w_s[axis][pb][i] != 0.f) { if (!any) { lo = i; any = true; } hi = i + 1; }
+        if (axis == 0) { h->ylo[pb] = lo; h->yhi[pb] = hi; } else { h->xlo[pb] = lo; h->xhi[pb] = hi; }
+        w_s[axis][pb][0] = (float)hi;  // reuse as scratch for the extents (column 0 is consumed above)
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int he = 0, we = 0;
+        for (int pb = 0; pb < 7; ++pb) {
+            if ((int)w_s[0][pb][0] > he) he = (int)w_s[0][pb][0];
+            if ((int)w_s[1][pb][0] > we) we = (int)w_s[1][pb][0];
+        }
+        h->hext = he; h->wext = we;
+    }
+}
+
+// ---- RoIAlign forward, separable form ---------------------------------------------------------------------------
+// out[c][ph][pw] = inv * sum_y wy[ph][y] * sum_x wx[pw][x] * F[c][y][x] over the RoI's feature window, using the
+// per-RoI weight tables above.  One workgroup = (RoI of any set, RF_CH channels); a wave owns one channel at a
+// time with lanes along the window's columns, so every feature row is ONE coalesced read (the sampling form
+// issues 4 gathers per sample point), accumulates U[ph] per column while walking down the rows, and finishes
+// with a 49-lane contraction over columns through LDS.  Windows wider/taller than RW_EXT (extreme aspect
+// ratios) take the sampling form inside the same kernel.
+constexpr int RF_CH = 64;
+__global__ __launch_bounds__(256) void roialign_fwd_sep_kernel(RoiLevels L, RoiSets S, int P, int sample_num,
+                                                               const RoiWeightHdr* __restrict__ hdr,
+                                                               const float* __restrict__ wtab, float* __restrict__ out,
+                                                               int64_t out_roi_stride) {
+    __shared__ float wy_s[7][RW_EXT], wx_s[7][RW_EXT];
+    __shared__ float U_s[4][7][RW_EXT];
+    __shared__ RoiWeightHdr h_s;
+    const int id = blockIdx.x;
+    const int s = id / S.R, k = id - s * S.R;
+    const int c0 = blockIdx.y * RF_CH;
+    const int ncc = L.C - c0 < RF_CH ? L.C - c0 : RF_CH;
+    int lvl = (int)S.levels[s][k];
+    lvl = lvl < 0 ? 0 : (lvl >= L.n ? L.n - 1 : lvl);
+    int H = L.H[0], W = L.W[0];
+    const float* feat = L.feat[0];
+#pragma unroll
+    for (int i = 1; i < ARFE_MAX_LEVELS; ++i)
+        if (i == lvl) { H = L.H[i]; W = L.W[i]; feat = L.feat[i]; }
+    const float* roi = S.rois[s] + 5 * (int64_t)k;
+    const int bimg = (int)roi[0];
+    float* obase = out + (int64_t)k * out_roi_stride + ((int64_t)s * L.C + c0) * 49;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int big = hdr[id].big;
+
+    if (big == 2) {     // every sample falls outside the feature map (or negative size): zeros
+        for (int o = tid; o < ncc * 49; o += 256) obase[o] = 0.f;
+        return;
+    }
+    if (big) {          // sampling form (reference order), one thread per output element
+        const RoiGeom g = roi_geom(roi, L.scale[lvl], P, sample_num);
+        for (int o = tid; o < ncc * 49; o += 256) {
+            const int c = o / 49, q = o - c * 49, ph = q / 7, pw = q - ph * 7;
+            const float* f = feat + ((int64_t)bimg * L.C + c0 + c) * H * W;
+            float acc = 0.f;
+            for (int iy = 0; iy < g.grid_h; ++iy) {
+                const float yy = g.y_start + ph * g.bin_h + ((float)iy + 0.5f) * g.bin_h / (float)g.grid_h;
+                int y0, y1; float wy0, wy1;
+                const bool oky = axis_tap(yy, H, y0, y1, wy0, wy1);
+                for (int ix = 0; ix < g.grid_w; ++ix) {
+                    const float xx = g.x_start + pw * g.bin_w + ((float)ix + 0.5f) * g.bin_w / (float)g.grid_w;
+                    int x0, x1; float wx0, wx1;
+                    const bool okx = axis_tap(xx, W, x0, x1, wx0, wx1);
+                    if (!(oky && okx)) continue;
+                    acc += wy0 * wx0 * f[y0 * W + x0] + wy0 * wx1 * f[y0 * W + x1] + wy1 * wx0 * f[y1 * W + x0] +
+                           wy1 * wx1 * f[y1 * W + x1];
+                }
+            }
+            obase[o] = acc / g.count;
+        }
+        return;
+    }
+    // ---- header + weight tables -> LDS ----
+    if (tid < (int)(sizeof(RoiWeightHdr) / sizeof(int))) ((int*)&h_s)[tid] = ((const int*)(hdr + id))[tid];
+    const float* wt = wtab + (int64_t)id * 2 * 7 * RW_EXT;
+    const float inv = hdr[id].inv;
+    for (int i = tid; i < 7 * RW_EXT; i += 256) {
+        (&wy_s[0][0])[i] = wt[i] * inv;
+        (&wx_s[0][0])[i] = wt[7 * RW_EXT + i];
+    }
+    __syncthreads();
+    const int wext = h_s.wext;
+    // windows up to 32 columns wide (the common case) put two channels on one wave
+    const int pack = wext <= 32 ? 2 : 1;
+    const int half = pack == 2 ? lane >> 5 : 0;
+    const int col = pack == 2 ? lane & 31 : lane;
+    const bool col_ok = col < wext;
+    const int q = lane < 49 ? lane : 48, qph = q / 7, qpw = q - qph * 7;
+    const int xlo = h_s.xlo[qpw], xhi = h_s.xhi[qpw];
+    for (int cb = wave * pack; cb < ncc; cb += 4 * pack) {
+        const int c = cb + half;
+        const bool c_ok = c < ncc && col_ok;
+        const float* f = feat + (((int64_t)bimg * L.C + c0 + (c < ncc ? c : cb)) * H + h_s.y0) * W + h_s.x0 + col;
+#pragma unroll
+        for (int ph = 0; ph < 7; ++ph) {
+            float acc = 0.f;
+            const int ylo = h_s.ylo[ph], yhi = h_s.yhi[ph];
+#pragma unroll 4
+            for (int y = ylo; y < yhi; ++y) acc += wy_s[ph][y] * (c_ok ? f[(int64_t)y * W] : 0.f);
+            U_s[wave][ph][lane] = acc;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);     // lgkmcnt(0): this wave's U_s writes have landed
+        __builtin_amdgcn_wave_barrier();
+        for (int hh = 0; hh < pack; ++hh) {
+            if (lane < 49 && cb + hh < ncc) {
+                float acc = 0.f;
+                for (int x = xlo; x < xhi; ++x) acc += U_s[wave][qph][hh * 32 + x] * wx_s[qpw][x];
+                obase[(cb + hh) * 49 + lane] = acc;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -316,10 +408,11 @@ __global__ __launch_bounds__(256) void roialign_bwd_tiles_kernel(RoiLevels L, Ro
             const int s = id / S.R, k = id - s * S.R;
             // ---- A: this tile's slice of the RoI's 1-D weight tables (threads 0..111 rows, 128..239 columns) ----
             if (tid < RT * 7 || (tid >= 128 && tid < 128 + RT * 7)) {
-                const RoiWeightHdr h = hdr[id];
+                const RoiWeightHdr* hp = hdr + id;
+                struct { int y0, x0, big; float inv; } h = {hp->y0, hp->x0, hp->big, hp->inv};
                 const int axis = tid >> 7, u = tid & 127, r = u / 7, pb = u - r * 7;
                 float w;
-                if (!h.big) {
+                if (h.big == 0) {
                     const int off = (axis ? tx * RT - h.x0 : ty * RT - h.y0) + r;
                     w = (off >= 0 && off < RW_EXT) ? wtab[((int64_t)id * 2 + axis) * 7 * RW_EXT + pb * RW_EXT + off] : 0.f;
                 } else {
@@ -460,19 +553,38 @@ extern "C" int32_t arfe_map_roi_levels(int32_t R, const float* rois, int32_t num
     return ARFE_OK;
 }
 
+extern "C" int64_t arfe_roialign_fwd_workspace_bytes(int32_t nsets, int32_t R) {
+    if (nsets < 1 || nsets > RB_MAXSETS || R < 0) return -1;
+    return (int64_t)nsets * R * ((int64_t)sizeof(RoiWeightHdr) + (int64_t)2 * 7 * RW_EXT * sizeof(float)) + 64;
+}
+
 extern "C" int32_t arfe_roialign_fwd(const arfe_pyramid_t* pyr, const float* const* feats, const int32_t* strides,
-                                     int32_t R, const float* rois, const int64_t* levels, int32_t pooled,
-                                     int32_t sample_num, float* out, int64_t out_roi_stride, void* stream) {
+                                     int32_t nsets, int32_t R, const float* const* rois, const int64_t* const* levels,
+                                     int32_t pooled, int32_t sample_num, float* out, int64_t out_roi_stride,
+                                     void* workspace, void* stream) {
     int32_t rc = check_pyramid(pyr);
     if (rc) return rc;
-    ARFE_CHECK_ARG(R >= 0 && pooled > 0 && pooled <= 16 && sample_num >= 0, ARFE_ERR_ARG, "roialign_fwd: bad arguments");
+    ARFE_CHECK_ARG(R >= 0 && nsets >= 1 && nsets <= RB_MAXSETS && sample_num >= 0, ARFE_ERR_ARG, "roialign_fwd: bad arguments");
+    ARFE_CHECK_ARG(pooled == 7, ARFE_ERR_ARG, "roialign_fwd: only 7x7 pooling has a kernel (got %d)", pooled);
     if (R == 0) return ARFE_OK;
-    ARFE_CHECK_ARG(feats && strides && rois && levels && out, ARFE_ERR_ARG, "roialign_fwd: null pointer");
+    ARFE_CHECK_ARG(feats && strides && rois && levels && out && workspace, ARFE_ERR_ARG, "roialign_fwd: null pointer");
     RoiLevels L;
     ARFE_CHECK_ARG(fill_roi_levels(L, pyr, feats, nullptr, strides) == ARFE_OK, ARFE_ERR_ARG, "roialign_fwd: bad level table");
-    const int64_t total = (int64_t)R * L.C * pooled * pooled;
-    hipLaunchKernelGGL(roialign_fwd_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, as_stream(stream), L, R, rois,
-                       levels, pooled, sample_num, out, out_roi_stride);
+    RoiSets S;
+    S.nsets = nsets; S.R = R;
+    for (int i = 0; i < RB_MAXSETS; ++i) { S.rois[i] = nullptr; S.levels[i] = nullptr; }
+    for (int i = 0; i < nsets; ++i) {
+        ARFE_CHECK_ARG(rois[i] && levels[i], ARFE_ERR_ARG, "roialign_fwd: null RoI set %d", i);
+        S.rois[i] = rois[i]; S.levels[i] = levels[i];
+    }
+    const int nroi = nsets * R;
+    RoiWeightHdr* hdr = (RoiWeightHdr*)workspace;
+    float* wtab = (float*)(hdr + nroi);
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(roi_weight_table_kernel, dim3(nroi), dim3(256), 0, st, L, S, pooled, sample_num, hdr, wtab);
+    ARFE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(roialign_fwd_sep_kernel, dim3(nroi, cdiv(L.C, RF_CH)), dim3(256), 0, st, L, S, pooled, sample_num,
+                       (const RoiWeightHdr*)hdr, (const float*)wtab, out, out_roi_stride);
     ARFE_CHECK_LAUNCH();
     return ARFE_OK;
 }

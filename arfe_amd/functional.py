@@ -257,15 +257,16 @@ def _stride_array(strides):
     return arr
 
 
-def roialign_fwd_op(feats, strides, rois, levels, out, chan_offset, pooled=7, sample_num=0):
-    """Writes RoIAlign(feats[levels[k]], rois[k]) into out[:, chan_offset:chan_offset+C] in place."""
-    hip.require_f32_cuda(*feats, rois, out)
+def roialign_fwd_op(feats, strides, roi_sets, level_sets, out, pooled=7, sample_num=0):
+    """RoIAlign of every set into its channel slice of `out` [R, nsets*C, 7, 7] (one launch for all sets)."""
+    hip.require_f32_cuda(*feats, *roi_sets, out)
     pyr = Pyramid.of(feats, 0)
-    view = out[:, chan_offset:]
+    nsets, R = len(roi_sets), roi_sets[0].shape[0]
+    ws = _ws(hip.lib().arfe_roialign_fwd_workspace_bytes(nsets, R), out.device)
     with probe('roialign_fwd'):
-      check(hip.lib().arfe_roialign_fwd(ctypes.byref(pyr), ptr_array(feats), _stride_array(strides), rois.shape[0],
-                                      ptr(rois), ptr(levels), pooled, sample_num, view.data_ptr(), out.stride(0),
-                                      stream()), "arfe_roialign_fwd")
+        check(hip.lib().arfe_roialign_fwd(ctypes.byref(pyr), ptr_array(feats), _stride_array(strides), nsets, R,
+                                          ptr_array(roi_sets), ptr_array(level_sets), pooled, sample_num, ptr(out),
+                                          out.stride(0), ptr(ws), stream()), "arfe_roialign_fwd")
 
 
 def roialign_bwd_op(shapes, strides, roi_sets, level_sets, gout, pooled=7, sample_num=0):
@@ -293,11 +294,9 @@ class RoIExtractFunction(torch.autograd.Function):
         feats = [f.contiguous() for f in t[nsets:]]
         R, C = roi_sets[0].shape[0], feats[0].shape[1]
         out = torch.empty(R, nsets * C, pooled, pooled, device=feats[0].device)
-        levels = []
-        for s, rois in enumerate(roi_sets):
-            lv = map_roi_levels_op(rois, len(feats), finest_scale)
-            roialign_fwd_op(feats, strides, rois, lv, out, s * C, pooled, sample_num)
-            levels.append(lv)
+        levels = [map_roi_levels_op(rois, len(feats), finest_scale) for rois in roi_sets]
+        if R > 0:
+            roialign_fwd_op(feats, strides, roi_sets, levels, out, pooled, sample_num)
         ctx.cfg = (tuple(strides), pooled, sample_num, nsets, C)
         ctx.shapes = [f.shape for f in feats]
         ctx.save_for_backward(*roi_sets, *levels)

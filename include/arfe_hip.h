@@ -128,12 +128,16 @@ int32_t arfe_map_roi_levels(int32_t R, const float* rois, int32_t num_levels, fl
 
 /* RoIAlign v2 (aligned=True, sample_num=0 -> adaptive grid; mmdet/ops/roi_align/src/cpu/roi_align_v2.cpp
  * :107-191 fwd, :247-332 bwd; CUDA kernels src/cuda/roi_align_kernel_v2.cu:63-129,180-) fused with the
- * per-level dispatch of SingleRoIExtractor.forward (single_level.py:109-152): RoI k samples level levels[k]
- * with spatial scale 1/strides[level].  out is written at out + k*out_roi_stride + c*P*P (so three calls fill
- * the [R, 3C, 7, 7] concat of standard_roi_head.py:155 in place). */
+ * per-level dispatch of SingleRoIExtractor.forward (single_level.py:109-152) for `nsets` RoI sets at once:
+ * RoI k of set s samples level levels[s][k] with spatial scale 1/strides[level] and is written at
+ * out + k*out_roi_stride + (s*C + c)*49 + p, i.e. the three sets of the AR-RFF path fill the [R, 3C, 7, 7]
+ * concat of standard_roi_head.py:155 in place.  pooled must be 7.
+ * workspace: arfe_roialign_fwd_workspace_bytes(nsets, R) (per-RoI separable weight tables). */
+int64_t arfe_roialign_fwd_workspace_bytes(int32_t nsets, int32_t R);
 int32_t arfe_roialign_fwd(const arfe_pyramid_t* pyr, const float* const* feats, const int32_t* strides,
-                          int32_t R, const float* rois, const int64_t* levels, int32_t pooled,
-                          int32_t sample_num, float* out, int64_t out_roi_stride, void* stream);
+                          int32_t nsets, int32_t R, const float* const* rois, const int64_t* const* levels,
+                          int32_t pooled, int32_t sample_num, float* out, int64_t out_roi_stride,
+                          void* workspace, void* stream);
 
 /* dfeats[i] = sum over all `nsets` RoI sets of RoIAlign^T(gout slice of that set): every element of every
  * dfeats[i] is written by the call (zero-filled first; a 16x16 tile whose RoI list is long is summed by a few
