@@ -82,12 +82,22 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmDims d, LA la, 
     }
     float ra[2][8], rb[2][8];
     auto fetch = [&](int step) {
-        const int kb = step / ksteps_per_kb;
-        const int k0 = (step - kb * ksteps_per_kb) * XB_BK;
+        // k-batch outermost (default) or innermost (kb_inner: the same K-slice of every k-batch back to back,
+        // e.g. the 9 taps of a 3x3 conv re-use one staged channel slice while it is still in L1/L2)
+        const int kb = d.kb_inner ? step % d.kb_count : step / ksteps_per_kb;
+        const int k0 = (d.kb_inner ? step / d.kb_count : step - kb * ksteps_per_kb) * XB_BK;
+        const bool full_k = k0 + XB_BK <= d.K;      // wave-uniform: every step but a K tail skips the k bound checks
+        if (full_k) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) la.load8(arow[i], z, kb, k0 + 8 * a_oct[i], ra[i]);
+            for (int i = 0; i < 2; ++i) la.template load8<true>(arow[i], z, kb, k0 + 8 * a_oct[i], ra[i]);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) lb.load8(brow[i], z, kb, k0 + 8 * b_oct[i], rb[i]);
+            for (int i = 0; i < 2; ++i) lb.template load8<true>(brow[i], z, kb, k0 + 8 * b_oct[i], rb[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) la.template load8<false>(arow[i], z, kb, k0 + 8 * a_oct[i], ra[i]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) lb.template load8<false>(brow[i], z, kb, k0 + 8 * b_oct[i], rb[i]);
+        }
     };
     auto stash = [&]() {
 #pragma unroll
@@ -160,11 +170,12 @@ bool gemm_use_f32();
 
 template <class LA, class LB, class EPI>
 static inline int32_t launch_gemm_auto(int M, int N, int K, int kb_count, int batch, int splitk, LA la, LB lb, EPI epi,
-                                       hipStream_t stream, bool exact = false) {
-    if (exact || gemm_use_f32()) return launch_gemm(M, N, K, kb_count, batch, splitk, la, lb, epi, stream);
+                                       hipStream_t stream, bool exact = false, bool kb_inner = false) {
+    if (exact || gemm_use_f32()) return launch_gemm(M, N, K, kb_count, batch, splitk, la, lb, epi, stream, kb_inner);
     if (M <= 0 || N <= 0 || batch <= 0) return ARFE_OK;
     GemmDims d;
     d.M = M; d.N = N; d.K = K; d.kb_count = kb_count < 1 ? 1 : kb_count;
+    d.kb_inner = kb_inner ? 1 : 0;
     d.tiles_m = cdiv(M, GEMM_BM); d.tiles_n = cdiv(N, GEMM_BN);
     d.ksteps_total = d.kb_count * cdiv(K, XB_BK);
     if (splitk < 1) splitk = 1;

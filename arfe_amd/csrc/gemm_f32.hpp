@@ -29,6 +29,7 @@ struct GemmDims {
     int tiles_m, tiles_n;
     int splitk;         // gridDim.y
     int ksteps_total;   // kb_count * ceil(K / BK)
+    int kb_inner;       // 1: iterate k-batches innermost
 };
 
 // ---- operand loaders: return A(m,k) / B(k,n) for batch z and k-batch kb, 0 outside the matrix ------------
@@ -48,6 +49,9 @@ __device__ __forceinline__ void ld8_contig(const float* q, float (&v)[8]) {
     v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
 }
 
+// Octet loads are branch-free: rows are clamped into the matrix by row() (an `ok` flag zeroes them afterwards) and
+// FULLK (K a multiple of the K-step, decided once per launch) removes every k bound check, so all loads of a
+// K-step are issued back to back instead of sitting in divergent branches.
 struct LoadRowMajorK {   // element(i, k) = p[z*sz + kb*skb + i*ld + k]     (k contiguous)
     const float* p; int64_t sz, skb; int64_t ld; int rows, K;
     static constexpr bool kfast = true;
@@ -55,14 +59,23 @@ struct LoadRowMajorK {   // element(i, k) = p[z*sz + kb*skb + i*ld + k]     (k c
         return (i < rows && k < K) ? p[z * sz + kb * skb + (int64_t)i * ld + k] : 0.f;
     }
     struct Row { const float* q; bool ok; };
-    __device__ __forceinline__ Row row(int z, int i) const { return Row{p + z * sz + (int64_t)i * ld, i < rows}; }
+    __device__ __forceinline__ Row row(int z, int i) const {
+        return Row{p + z * sz + (int64_t)(i < rows ? i : rows - 1) * ld, i < rows};
+    }
+    template <bool FULLK>
     __device__ __forceinline__ void load8(const Row& r, int, int kb, int k0, float (&v)[8]) const {
-        if (!r.ok) { zero8(v); return; }
-        const float* q = r.q + kb * skb + k0;
-        if (k0 + 7 < K) ld8_contig(q, v);
-        else {
+        const float* q = r.q + kb * skb;
+        if (FULLK) {
+            ld8_contig(q + k0, v);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = k0 + j < K ? q[j] : 0.f;
+            for (int j = 0; j < 8; ++j) v[j] = r.ok ? v[j] : 0.f;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = k0 + j;
+                const float t = q[k < K ? k : K - 1];
+                v[j] = (r.ok && k < K) ? t : 0.f;
+            }
         }
     }
 };
@@ -73,12 +86,16 @@ struct LoadRowMajorI {   // element(i, k) = p[z*sz + kb*skb + k*ld + i]     (i c
         return (i < rows && k < K) ? p[z * sz + kb * skb + (int64_t)k * ld + i] : 0.f;
     }
     struct Row { const float* q; bool ok; };
-    __device__ __forceinline__ Row row(int z, int i) const { return Row{p + z * sz + i, i < rows}; }
+    __device__ __forceinline__ Row row(int z, int i) const { return Row{p + z * sz + (i < rows ? i : rows - 1), i < rows}; }
+    template <bool FULLK>
     __device__ __forceinline__ void load8(const Row& r, int, int kb, int k0, float (&v)[8]) const {
-        if (!r.ok) { zero8(v); return; }
-        const float* q = r.q + kb * skb + (int64_t)k0 * ld;
+        const float* q = r.q + kb * skb;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = k0 + j < K ? q[(int64_t)j * ld] : 0.f;
+        for (int j = 0; j < 8; ++j) {
+            const int k = k0 + j;
+            const float t = q[(int64_t)(FULLK || k < K ? k : K - 1) * ld];
+            v[j] = (r.ok && (FULLK || k < K)) ? t : 0.f;
+        }
     }
 };
 
@@ -144,8 +161,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmDims d, LA la, LB 
     // per-thread staging coordinates: 8 elements of A and 8 of B per K-step
     float ra[8], rb[8];
     auto fetch = [&](int step) {
-        const int kb = step / ksteps_per_kb;
-        const int k0 = (step - kb * ksteps_per_kb) * GEMM_BK;
+        // k-batch outermost (default) or innermost (kb_inner: the same K-slice of every k-batch back to back,
+        // e.g. the 9 taps of a 3x3 conv re-use one staged channel slice while it is still in L1/L2)
+        const int kb = d.kb_inner ? step % d.kb_count : step / ksteps_per_kb;
+        const int k0 = (d.kb_inner ? step / d.kb_count : step - kb * ksteps_per_kb) * GEMM_BK;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             int mi, ki;
@@ -224,10 +243,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmDims d, LA la, LB 
 
 template <class LA, class LB, class EPI>
 static inline int32_t launch_gemm(int M, int N, int K, int kb_count, int batch, int splitk, LA la, LB lb, EPI epi,
-                                  hipStream_t stream) {
+                                  hipStream_t stream, bool kb_inner = false) {
     if (M <= 0 || N <= 0 || batch <= 0) return ARFE_OK;
     GemmDims d;
     d.M = M; d.N = N; d.K = K; d.kb_count = kb_count < 1 ? 1 : kb_count;
+    d.kb_inner = kb_inner ? 1 : 0;
     d.tiles_m = cdiv(M, GEMM_BM); d.tiles_n = cdiv(N, GEMM_BN);
     d.ksteps_total = d.kb_count * cdiv(K, GEMM_BK);
     if (splitk < 1) splitk = 1;

@@ -7,68 +7,9 @@ namespace arfe {
 // ---------------------------------------------------------------------------------------------------------
 // loaders with an optional ReLU mask (value is zeroed where mask <= 0; mask shares the value's indexing)
 // ---------------------------------------------------------------------------------------------------------
-struct LoadMaskedK {   // element(i,k) = p[i*ld + k] * [mask[i*ld+k] > 0]
-    const float* p; const float* mask; int64_t ld; int rows, K;
-    static constexpr bool kfast = true;
-    __device__ __forceinline__ float operator()(int, int, int i, int k) const {
-        if (i >= rows || k >= K) return 0.f;
-        int64_t o = (int64_t)i * ld + k;
-        float v = p[o];
-        if (mask && !(mask[o] > 0.f)) v = 0.f;
-        return v;
-    }
-    struct Row { int64_t o; bool ok; };
-    __device__ __forceinline__ Row row(int, int i) const { return Row{(int64_t)i * ld, i < rows}; }
-    __device__ __forceinline__ void load8(const Row& r, int, int, int k0, float (&v)[8]) const {
-        if (!r.ok) { zero8(v); return; }
-        if (k0 + 7 < K) {
-            ld8_contig(p + r.o + k0, v);
-            if (mask) {
-                float m[8];
-                ld8_contig(mask + r.o + k0, m);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) if (!(m[j] > 0.f)) v[j] = 0.f;
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float t = 0.f;
-                if (k0 + j < K) { t = p[r.o + k0 + j]; if (mask && !(mask[r.o + k0 + j] > 0.f)) t = 0.f; }
-                v[j] = t;
-            }
-        }
-    }
-};
-struct LoadMaskedI {   // element(i,k) = p[k*ld + i] * [mask > 0]
-    const float* p; const float* mask; int64_t ld; int rows, K;
-    static constexpr bool kfast = false;
-    __device__ __forceinline__ float operator()(int, int, int i, int k) const {
-        if (i >= rows || k >= K) return 0.f;
-        int64_t o = (int64_t)k * ld + i;
-        float v = p[o];
-        if (mask && !(mask[o] > 0.f)) v = 0.f;
-        return v;
-    }
-    struct Row { int i; bool ok; };
-    __device__ __forceinline__ Row row(int, int i) const { return Row{i, i < rows}; }
-    __device__ __forceinline__ void load8(const Row& r, int, int, int k0, float (&v)[8]) const {
-        if (!r.ok) { zero8(v); return; }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float t = 0.f;
-            if (k0 + j < K) {
-                const int64_t o = (int64_t)(k0 + j) * ld + r.i;
-                t = p[o];
-                if (mask && !(mask[o] > 0.f)) t = 0.f;
-            }
-            v[j] = t;
-        }
-    }
-};
-
 // ---- 3x3 conv on [R,C,7,7] RoI tiles as 9 shifted GEMMs (k-batch = tap) ------------------------------------
 struct ConvGatherB {   // B(n=(r,p), k=ci) for tap kb: x[r*roi_stride + ci*49 + shift(p, tap)], 0 outside the 7x7 tile
-    const float* x; const float* mask; int64_t roi_stride, mask_roi_stride; int N, Cin;
+    const float* x; int64_t roi_stride; int N, Cin;
     static constexpr bool kfast = false;
     __device__ __forceinline__ float operator()(int, int kb, int n, int k) const {
         if (n >= N || k >= Cin) return 0.f;
@@ -76,33 +17,29 @@ struct ConvGatherB {   // B(n=(r,p), k=ci) for tap kb: x[r*roi_stride + ci*49 + 
         int py = p / 7, px = p - py * 7;
         int yy = py + kb / 3 - 1, xx = px + kb % 3 - 1;
         if ((unsigned)yy >= 7u || (unsigned)xx >= 7u) return 0.f;
-        int q = k * 49 + yy * 7 + xx;
-        float v = x[(int64_t)r * roi_stride + q];
-        if (mask && !(mask[(int64_t)r * mask_roi_stride + q] > 0.f)) v = 0.f;
-        return v;
+        return x[(int64_t)r * roi_stride + k * 49 + yy * 7 + xx];
     }
-    struct Row { const float* xb; const float* mb; int py, px; bool ok; };
+    struct Row { const float* xb; int py, px; bool ok; };
     __device__ __forceinline__ Row row(int, int n) const {
         Row r;
         r.ok = n < N;
-        const int ri = n / 49, p = n - ri * 49;
+        const int nn = r.ok ? n : N - 1;
+        const int ri = nn / 49, p = nn - ri * 49;
         r.py = p / 7; r.px = p - r.py * 7;
         r.xb = x + (int64_t)ri * roi_stride;
-        r.mb = mask ? mask + (int64_t)ri * mask_roi_stride : nullptr;
         return r;
     }
+    template <bool FULLK>
     __device__ __forceinline__ void load8(const Row& r, int, int kb, int k0, float (&v)[8]) const {
         const int yy = r.py + kb / 3 - 1, xx = r.px + kb % 3 - 1;
-        if (!r.ok || (unsigned)yy >= 7u || (unsigned)xx >= 7u) { zero8(v); return; }
-        const int q0 = k0 * 49 + yy * 7 + xx;
+        const bool inside = r.ok && (unsigned)yy < 7u && (unsigned)xx < 7u;
+        // padding taps read a valid (clamped) address and are zeroed: no branch, all 8 loads issue together
+        const float* q = r.xb + (inside ? yy * 7 + xx : 0);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            float t = 0.f;
-            if (k0 + j < Cin) {
-                t = r.xb[q0 + j * 49];
-                if (r.mb && !(r.mb[q0 + j * 49] > 0.f)) t = 0.f;
-            }
-            v[j] = t;
+            const int k = k0 + j;
+            const float t = q[(FULLK || k < Cin ? k : Cin - 1) * 49];
+            v[j] = (inside && (FULLK || k < Cin)) ? t : 0.f;
         }
     }
 };
@@ -116,67 +53,60 @@ struct EpiConv {       // y[r*roi_stride + co*49 + p] = act(v + bias[co]) * [mas
         y[(int64_t)r * roi_stride + m * 49 + p] = v;
     }
 };
-struct WgradA {        // A(m=co, k=(r,p)) = dy[r*roi_stride + co*49 + p] * [relu_out > 0]
-    const float* dy; const float* mask; int64_t roi_stride; int Cout, K;
+
+// Weight gradient of the 3x3 conv: reduction index k' = r*56 + p with the 49 pixels of an RoI padded to 7 octets
+// (p >= 49 is zero), so a k-octet never straddles two RoIs: K' = R*56.
+constexpr int WG_PAD = 56;
+struct WgradA {        // A(m=co, k') = dy[r*roi_stride + co*49 + p]
+    const float* dy; int64_t roi_stride; int Cout, R;
     static constexpr bool kfast = true;
     __device__ __forceinline__ float operator()(int, int, int m, int k) const {
-        if (m >= Cout || k >= K) return 0.f;
-        int r = k / 49, p = k - r * 49;
-        int64_t o = (int64_t)r * roi_stride + m * 49 + p;
-        float v = dy[o];
-        if (mask && !(mask[o] > 0.f)) v = 0.f;
-        return v;
+        const int r = k / WG_PAD, p = k - r * WG_PAD;
+        if (m >= Cout || r >= R || p >= 49) return 0.f;
+        return dy[(int64_t)r * roi_stride + m * 49 + p];
     }
-    struct Row { int m; bool ok; };
-    __device__ __forceinline__ Row row(int, int m) const { return Row{m, m < Cout}; }
-    __device__ __forceinline__ void load8(const Row& r, int z, int kb, int k0, float (&v)[8]) const {
-        if (!r.ok) { zero8(v); return; }
-        const int ri = k0 / 49, p0 = k0 - ri * 49;
-        if (p0 + 7 < 49 && k0 + 7 < K) {          // the octet stays inside one RoI: 8 contiguous floats
-            const int64_t o = (int64_t)ri * roi_stride + r.m * 49 + p0;
-            ld8_contig(dy + o, v);
-            if (mask) {
-                float m8[8];
-                ld8_contig(mask + o, m8);
+    struct Row { const float* q; bool ok; };
+    __device__ __forceinline__ Row row(int, int m) const { return Row{dy + (m < Cout ? m : Cout - 1) * 49, m < Cout}; }
+    template <bool FULLK>
+    __device__ __forceinline__ void load8(const Row& r, int, int, int k0, float (&v)[8]) const {
+        const int o8 = k0 >> 3, ri = o8 / 7, oc = o8 - ri * 7;          // octet oc of RoI ri
+        const bool ok = r.ok && ri < R;
+        const float* q = r.q + (int64_t)(ri < R ? ri : R - 1) * roi_stride;
+        // octets 0..5 are 8 contiguous pixels; octet 6 holds only p = 48: read pixels 41..48 and keep the last
+        float t[8];
+        ld8_contig(q + (oc < 6 ? oc * 8 : 41), t);
+        v[0] = ok ? (oc < 6 ? t[0] : t[7]) : 0.f;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) if (!(m8[j] > 0.f)) v[j] = 0.f;
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (*this)(z, kb, r.m, k0 + j);
-        }
+        for (int j = 1; j < 8; ++j) v[j] = (ok && oc < 6) ? t[j] : 0.f;
     }
 };
-struct WgradB {        // B(n=ci, k=(r,p)) for tap z: x[r*roi_stride + ci*49 + shift(p, tap)]
-    const float* x; int64_t roi_stride; int Cin, K;
+struct WgradB {        // B(n=ci, k') for tap z: x[r*roi_stride + ci*49 + shift(p, tap)]
+    const float* x; int64_t roi_stride; int Cin, R;
     static constexpr bool kfast = true;
     __device__ __forceinline__ float operator()(int z, int, int n, int k) const {
-        if (n >= Cin || k >= K) return 0.f;
-        int r = k / 49, p = k - r * 49;
+        const int r = k / WG_PAD, p = k - r * WG_PAD;
+        if (n >= Cin || r >= R || p >= 49) return 0.f;
         int py = p / 7, px = p - py * 7;
         int yy = py + z / 3 - 1, xx = px + z % 3 - 1;
         if ((unsigned)yy >= 7u || (unsigned)xx >= 7u) return 0.f;
         return x[(int64_t)r * roi_stride + n * 49 + yy * 7 + xx];
     }
-    struct Row { int n; bool ok; };
-    __device__ __forceinline__ Row row(int, int n) const { return Row{n, n < Cin}; }
-    __device__ __forceinline__ void load8(const Row& r, int z, int kb, int k0, float (&v)[8]) const {
-        if (!r.ok) { zero8(v); return; }
-        const int ri = k0 / 49, p0 = k0 - ri * 49;
-        const int dyo = z / 3 - 1, dxo = z % 3 - 1, off = dyo * 7 + dxo;
-        // inside one RoI and the shifted window [p0+off, p0+off+7] inside the channel's 49 floats:
-        // one contiguous read, then the per-pixel padding mask
-        if (p0 + 7 < 49 && k0 + 7 < K && p0 + off >= 0 && p0 + off + 7 < 49) {
-            ld8_contig(x + (int64_t)ri * roi_stride + r.n * 49 + p0 + off, v);
-            int py = p0 / 7, px = p0 - py * 7;
+    struct Row { const float* q; bool ok; };
+    __device__ __forceinline__ Row row(int, int n) const { return Row{x + (n < Cin ? n : Cin - 1) * 49, n < Cin}; }
+    template <bool FULLK>
+    __device__ __forceinline__ void load8(const Row& r, int z, int, int k0, float (&v)[8]) const {
+        const int o8 = k0 >> 3, ri = o8 / 7, oc = o8 - ri * 7;
+        const bool ok = r.ok && ri < R;
+        const float* q = r.q + (int64_t)(ri < R ? ri : R - 1) * roi_stride;
+        const int dyo = z / 3 - 1, dxo = z % 3 - 1;
+        int py = (oc * 8) / 7, px = oc * 8 - py * 7;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                if ((unsigned)(py + dyo) >= 7u || (unsigned)(px + dxo) >= 7u) v[j] = 0.f;
-                if (++px == 7) { px = 0; ++py; }
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (*this)(z, kb, r.n, k0 + j);
+        for (int j = 0; j < 8; ++j) {
+            const int yy = py + dyo, xx = px + dxo;
+            const bool in = ok && oc * 8 + j < 49 && (unsigned)yy < 7u && (unsigned)xx < 7u;
+            const float t = q[in ? yy * 7 + xx : 0];
+            v[j] = in ? t : 0.f;
+            if (++px == 7) { px = 0; ++py; }
         }
     }
 };
@@ -493,9 +423,9 @@ extern "C" int32_t arfe_conv3x3_fwd(int32_t R, int32_t C, const float* x, int64_
     ARFE_CHECK_ARG(x && packed && y, ARFE_ERR_ARG, "conv3x3_fwd: null pointer");
     const float* wp = (const float*)packed;
     LoadRowMajorK la{wp, 0, (int64_t)C * C, C, C, C};     // A(m=co,k=ci) for tap kb
-    ConvGatherB lb{x, nullptr, x_roi_stride, 0, R * 49, C};
+    ConvGatherB lb{x, x_roi_stride, R * 49, C};
     EpiConv e{y, y_roi_stride, b, relu, nullptr, 0};
-    return launch_gemm_auto(C, R * 49, C, 9, 1, 1, la, lb, e, as_stream(stream));
+    return launch_gemm_auto(C, R * 49, C, 9, 1, 1, la, lb, e, as_stream(stream), /*exact=*/false, /*kb_inner=*/true);
 }
 
 extern "C" int32_t arfe_conv3x3_bwd_data(int32_t R, int32_t C, const void* packed, const float* dy,
@@ -506,9 +436,9 @@ extern "C" int32_t arfe_conv3x3_bwd_data(int32_t R, int32_t C, const void* packe
     ARFE_CHECK_ARG(packed && dy && dx, ARFE_ERR_ARG, "conv3x3_bwd_data: null pointer");
     const float* wd = (const float*)packed + (size_t)9 * C * C;
     LoadRowMajorK la{wd, 0, (int64_t)C * C, C, C, C};      // A(m=ci,k=co) = w[co][ci][8-tap]
-    ConvGatherB lb{dy, nullptr, dy_roi_stride, 0, R * 49, C};
+    ConvGatherB lb{dy, dy_roi_stride, R * 49, C};
     EpiConv e{dx, dx_roi_stride, nullptr, 0, dx_mask, dx_mask_roi_stride};
-    return launch_gemm_auto(C, R * 49, C, 9, 1, 1, la, lb, e, as_stream(stream));
+    return launch_gemm_auto(C, R * 49, C, 9, 1, 1, la, lb, e, as_stream(stream), /*exact=*/false, /*kb_inner=*/true);
 }
 
 extern "C" int32_t arfe_conv3x3_bwd_weight(int32_t R, int32_t C, const float* x, int64_t x_roi_stride,
@@ -525,13 +455,14 @@ extern "C" int32_t arfe_conv3x3_bwd_weight(int32_t R, int32_t C, const float* x,
     float* dwp = (float*)workspace;
     int total = 9 * C * C;
     if (hipMemsetAsync(dwp, 0, sizeof(float) * (size_t)total, st) != hipSuccess) return ARFE_ERR_LAUNCH;
-    WgradA la{dy, nullptr, dy_roi_stride, C, R * 49};
-    WgradB lb{x, x_roi_stride, C, R * 49};
-    int ksteps = cdiv(R * 49, gemm_bk());
+    WgradA la{dy, dy_roi_stride, C, R};
+    WgradB lb{x, x_roi_stride, C, R};
+    const int Kp = R * WG_PAD;
+    int ksteps = cdiv(Kp, gemm_bk());
     int splitk = pick_splitk(C, C, 9, ksteps);
     EpiPlain e = epi_plain(dwp, (int64_t)C * C, C);
     e.atomic = 1;
-    int32_t rc = launch_gemm_auto(C, C, R * 49, 1, 9, splitk, la, lb, e, st);
+    int32_t rc = launch_gemm_auto(C, C, Kp, 1, 9, splitk, la, lb, e, st);
     if (rc) return rc;
     hipLaunchKernelGGL(conv_dw_unpermute_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, dwp, dw, C);
     ARFE_CHECK_LAUNCH();

@@ -1,0 +1,11 @@
+#!/bin/bash
+# rocprofv3 PMC passes (no trace domains mixed in, as the pool requires); run on the GPU box from the repo root:
+#   bash tools/pmc_run.sh <outdir-under-gpurun_out> "<counter list>" <python script + args>
+set -e
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/$1; shift
+CTR="$1"; shift
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --pmc $CTR --kernel-trace --output-format csv -d $OUT -o pmc -- python3 "$@" > $OUT/run.log 2>&1 || (tail -5 $OUT/run.log; exit 1)
+ls $OUT
