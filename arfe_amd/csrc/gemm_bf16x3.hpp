@@ -165,8 +165,187 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmDims d, LA la, 
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Large-tile variant for the big contractions (3x3 convs, FC1, theta^T phi): 256x256x32 tile, 512 threads =
+// 8 waves as 2(M) x 4(N), wave tile 128x64 = 4x2 MFMA blocks (128 accumulator registers).  Against the 128x128
+// kernel every staged operand element feeds twice the MFMAs (LDS write traffic per flop halves; ds_write_b128
+// runs at only ~79 B/clk) and each fragment read feeds 1.5x the MFMAs.  The two LDS buffers (2 x 80 KB = the
+// whole 160 KB of a CU) give one barrier per K-step: iteration s splits+stores step s+1 into the other buffer and
+// issues the global loads of step s+2 around the 48 MFMAs of step s.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int XL_BM = 256, XL_BN = 256;
+constexpr int XL_LDS_BYTES = 2 * 2 * (XL_BM + XL_BN) * XB_LD * 2;      // 163840
+
+template <class LA, class LB, class EPI>
+__global__ __launch_bounds__(512, 2) void gemm_bf16x3_large_kernel(GemmDims d, LA la, LB lb, EPI epi) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short xl_lds[];
+    // buffer b: A_hi [256][40] | A_lo | B_hi | B_lo
+    auto img = [&](int buf, int which) -> unsigned short* {
+        return xl_lds + ((size_t)buf * 4 + which) * (XL_BM * XB_LD);
+    };
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int z = blockIdx.z;
+
+    int ntiles = d.tiles_m * d.tiles_n;
+    int bid = blockIdx.x;
+    {
+        int q = ntiles >> 3, r = ntiles & 7, x = bid & 7, j = bid >> 3;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+    }
+    const int tm = bid / d.tiles_n, tn = bid % d.tiles_n;
+    const int m0 = tm * XL_BM, n0 = tn * XL_BN;
+
+    const int ksteps_per_kb = (d.K + XB_BK - 1) / XB_BK;
+    const int per = (d.ksteps_total + d.splitk - 1) / d.splitk;
+    const int s_begin = blockIdx.y * per;
+    int s_end = s_begin + per;
+    if (s_end > d.ksteps_total) s_end = d.ksteps_total;
+    const bool first_split = (blockIdx.y == 0);
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // staging: operand tile = 256 rows x 4 k-octets = 1024 octets; two per thread and operand
+    int a_row[2], a_oct[2], b_row[2], b_oct[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (LA::kfast) { a_oct[i] = tid & 3; a_row[i] = (tid >> 2) + 128 * i; }
+        else           { a_row[i] = tid & 255; a_oct[i] = (tid >> 8) + 2 * i; }
+        if (LB::kfast) { b_oct[i] = tid & 3; b_row[i] = (tid >> 2) + 128 * i; }
+        else           { b_row[i] = tid & 255; b_oct[i] = (tid >> 8) + 2 * i; }
+    }
+    typename LA::Row arow[2];
+    typename LB::Row brow[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        arow[i] = la.row(z, m0 + a_row[i]);
+        brow[i] = lb.row(z, n0 + b_row[i]);
+    }
+    float ra[2][8], rb[2][8];
+    auto fetch = [&](int step) {
+        const int kb = d.kb_inner ? step % d.kb_count : step / ksteps_per_kb;
+        const int k0 = (d.kb_inner ? step / d.kb_count : step - kb * ksteps_per_kb) * XB_BK;
+        const bool full_k = k0 + XB_BK <= d.K;
+        if (full_k) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) la.template load8<true>(arow[i], z, kb, k0 + 8 * a_oct[i], ra[i]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) lb.template load8<true>(brow[i], z, kb, k0 + 8 * b_oct[i], rb[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) la.template load8<false>(arow[i], z, kb, k0 + 8 * a_oct[i], ra[i]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) lb.template load8<false>(brow[i], z, kb, k0 + 8 * b_oct[i], rb[i]);
+        }
+    };
+    auto stash_a = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            bf16x8 hi, lo;
+            split8(ra[i], hi, lo);
+            *reinterpret_cast<bf16x8*>(img(buf, 0) + a_row[i] * XB_LD + 8 * a_oct[i]) = hi;
+            *reinterpret_cast<bf16x8*>(img(buf, 1) + a_row[i] * XB_LD + 8 * a_oct[i]) = lo;
+        }
+    };
+    auto stash_b = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            bf16x8 hi, lo;
+            split8(rb[i], hi, lo);
+            *reinterpret_cast<bf16x8*>(img(buf, 2) + b_row[i] * XB_LD + 8 * b_oct[i]) = hi;
+            *reinterpret_cast<bf16x8*>(img(buf, 3) + b_row[i] * XB_LD + 8 * b_oct[i]) = lo;
+        }
+    };
+    const int kh = lane >> 5, l31 = lane & 31;
+    auto mma = [&](int buf, int kk) {
+        bf16x8 ah[4], al[4], bh[2], bl[2];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int ar = wm * 128 + t * 32 + l31;
+            ah[t] = *reinterpret_cast<const bf16x8*>(img(buf, 0) + ar * XB_LD + kk + 8 * kh);
+            al[t] = *reinterpret_cast<const bf16x8*>(img(buf, 1) + ar * XB_LD + kk + 8 * kh);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int br = wn * 64 + t * 32 + l31;
+            bh[t] = *reinterpret_cast<const bf16x8*>(img(buf, 2) + br * XB_LD + kk + 8 * kh);
+            bl[t] = *reinterpret_cast<const bf16x8*>(img(buf, 3) + br * XB_LD + kk + 8 * kh);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+            }
+    };
+
+    if (s_begin < s_end) {
+        fetch(s_begin);
+        stash_a(0);
+        stash_b(0);
+        if (s_begin + 1 < s_end) fetch(s_begin + 1);
+        __syncthreads();
+        int buf = 0;
+        for (int s = s_begin; s < s_end; ++s) {
+            const bool more = s + 1 < s_end;
+            // program order interleaves the VALU-heavy split/store of the next step with the two MFMA halves
+            if (more) stash_a(buf ^ 1);
+            mma(buf, 0);
+            if (more) stash_b(buf ^ 1);
+            if (s + 2 < s_end) fetch(s + 2);
+            mma(buf, 16);
+            __syncthreads();
+            buf ^= 1;
+        }
+    } else if (!first_split) {
+        return;
+    }
+
+    const int h = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + l31;
+            if (n >= d.N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m < d.M) epi(z, m, n, acc[i][j][r], first_split);
+            }
+        }
+}
+
 // precision mode of the dense contractions: bf16x3 by default, exact fp32 MFMA with ARFE_GEMM_F32=1
 bool gemm_use_f32();
+
+// The 256x256 kernel pays when the output holds enough large tiles to occupy the chip (one 8-wave workgroup per
+// CU).  When the caller allows K-slicing (splitk > 1: atomic epilogue into a zeroed output) the slice count is
+// re-derived for the large tile so that tiles x slices is about one workgroup per CU.
+static inline bool plan_large_tile(int M, int N, int batch, int ksteps, int* splitk) {
+    const int64_t tiles = (int64_t)cdiv(M, XL_BM) * cdiv(N, XL_BN) * batch;
+    const double fill = (double)M * N / ((double)cdiv(M, XL_BM) * XL_BM * (double)cdiv(N, XL_BN) * XL_BN);
+    if (fill < 0.85) return false;
+    int sk = 1;
+    if (*splitk > 1) {
+        sk = (int)(256 / (tiles > 0 ? tiles : 1));
+        const int max_s = ksteps / 4 > 1 ? ksteps / 4 : 1;
+        if (sk > max_s) sk = max_s;
+        if (sk < 1) sk = 1;
+    }
+    if (tiles * sk < 160) return false;
+    *splitk = sk;
+    return true;
+}
 
 template <class LA, class LB, class EPI>
 static inline int32_t launch_gemm_auto(int M, int N, int K, int kb_count, int batch, int splitk, LA la, LB lb, EPI epi,
@@ -176,11 +355,30 @@ static inline int32_t launch_gemm_auto(int M, int N, int K, int kb_count, int ba
     GemmDims d;
     d.M = M; d.N = N; d.K = K; d.kb_count = kb_count < 1 ? 1 : kb_count;
     d.kb_inner = kb_inner ? 1 : 0;
-    d.tiles_m = cdiv(M, GEMM_BM); d.tiles_n = cdiv(N, GEMM_BN);
     d.ksteps_total = d.kb_count * cdiv(K, XB_BK);
     if (splitk < 1) splitk = 1;
     if (splitk > d.ksteps_total && d.ksteps_total > 0) splitk = d.ksteps_total;
+    int splitk_large = splitk;
+    if (plan_large_tile(M, N, batch, d.ksteps_total, &splitk_large)) {
+        splitk = splitk_large;
+        d.splitk = splitk;
+        d.tiles_m = cdiv(M, XL_BM); d.tiles_n = cdiv(N, XL_BN);
+        static bool attr_set = false;      // per instantiation: opt in to the full 160 KB of LDS once
+        if (!attr_set) {
+            if (hipFuncSetAttribute((const void*)gemm_bf16x3_large_kernel<LA, LB, EPI>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, XL_LDS_BYTES) != hipSuccess) {
+                set_error("gemm: cannot reserve %d bytes of LDS", XL_LDS_BYTES);
+                return ARFE_ERR_LAUNCH;
+            }
+            attr_set = true;
+        }
+        dim3 grid(d.tiles_m * d.tiles_n, splitk, batch);
+        hipLaunchKernelGGL((gemm_bf16x3_large_kernel<LA, LB, EPI>), grid, dim3(512), XL_LDS_BYTES, stream, d, la, lb, epi);
+        ARFE_CHECK_LAUNCH();
+        return ARFE_OK;
+    }
     d.splitk = splitk;
+    d.tiles_m = cdiv(M, GEMM_BM); d.tiles_n = cdiv(N, GEMM_BN);
     dim3 grid(d.tiles_m * d.tiles_n, splitk, batch);
     hipLaunchKernelGGL((gemm_bf16x3_kernel<LA, LB, EPI>), grid, dim3(256), 0, stream, d, la, lb, epi);
     ARFE_CHECK_LAUNCH();
