@@ -79,6 +79,7 @@ struct TileTable {
 __global__ __launch_bounds__(256) void fpn_gate_partial_kernel(Levels lv, TileTable tt, LevelPtrs x, LevelPtrs w1,
                                                                LevelPtrs w2, float* __restrict__ pre, int64_t pre_total) {
     __shared__ __attribute__((aligned(16))) float tile[GT_CC][GT_H + 2][GT_LD];
+    __shared__ float wsm[GT_CC][18];
     int t = blockIdx.x, lvl = 0;
     while (lvl + 1 < lv.n && t >= tt.first_tile[lvl + 1]) ++lvl;
     t -= tt.first_tile[lvl];
@@ -122,14 +123,19 @@ __global__ __launch_bounds__(256) void fpn_gate_partial_kernel(Levels lv, TileTa
             if (c < c_end && gy >= 0 && gy < h && gx >= 0 && gx < w) v = xb[((int64_t)c * h + gy) * w + gx];
             tile[cc][rr][side ? 4 + GT_W : 3] = v;
         }
+        if (tid < GT_CC * 18) {            // this chunk's conv weights (both maps) next to the tile
+            const int cc = tid / 18, t = tid - cc * 18;
+            const int c = c0 + cc;
+            wsm[cc][t] = c < c_end ? (t < 9 ? W1[c * 9 + t] : W2[c * 9 + t - 9]) : 0.f;
+        }
         __syncthreads();
         // ---- 18 taps x 4 px per channel ----
 #pragma unroll 2
         for (int cc = 0; cc < GT_CC; ++cc) {
             const int c = c0 + cc;
             if (c >= c_end) break;
-            const float* k1 = W1 + c * 9;
-            const float* k2 = W2 + c * 9;
+            const float* k1 = &wsm[cc][0];
+            const float* k2 = &wsm[cc][9];
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
                 const float* r = &tile[cc][row + dy][4 * j + 3];
@@ -341,127 +347,172 @@ __global__ __launch_bounds__(256) void fpn_scatter_bwd_dbsf_kernel(Levels lv, Le
 
 // =========================================================================================================
 // backward C: dx = g + conv3x3^T(dpre_a; w1) + conv3x3^T(dpre_b; w2) + gather^T(dm / n)
+//   block = 64 pixel quads x 4 waves; a thread keeps the 3x6 neighbourhood of BOTH 1-channel gradient maps in
+//   registers (they do not depend on the channel) and each wave handles IB_CG consecutive channels: per channel one 16-B
+//   read of g, 18 scalar weight loads (wave-uniform), 72 FMAs, the pooling term and one 16-B store.
 // =========================================================================================================
-__global__ __launch_bounds__(256) void fpn_input_bwd_kernel(Levels lv, QuadTable qt, LevelPtrs gout, LevelPtrs dpa,
+constexpr int IB_CG = 8;
+struct BlockQuadTable {       // pixel quads (B*h*ceil(w/4)) of each level, in whole 64-quad blocks
+    int first_blk[NL_ + 1];
+    int64_t quads[NL_];
+    int wq[NL_];
+};
+// POW2: every level is an exact power-of-two multiple/fraction of the refine level (the padded pyramid): only the
+// shift-based index paths are compiled in (the generic paths made the kernel 167 KB of code at 256 VGPRs).
+template <bool POW2>
+__global__ __launch_bounds__(256) void fpn_input_bwd_kernel(Levels lv, BlockQuadTable bt, LevelPtrs gout, LevelPtrs dpa,
                                                             LevelPtrs dpb, LevelPtrs w1, LevelPtrs w2,
                                                             const float* __restrict__ dm, const int32_t* __restrict__ argmax,
                                                             LevelMutPtrs dx) {
-    int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= qt.first[lv.n]) return;
+    // The level is a function of blockIdx only (block-aligned table) and the wave index goes through readfirstlane,
+    // so level geometry, base pointers and the per-channel conv weights are all wave-uniform (scalar loads).
+    const int lq = threadIdx.x & 63, cw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int lvl = 0;
-    while (lvl + 1 < lv.n && q >= qt.first[lvl + 1]) ++lvl;
-    q -= qt.first[lvl];
-    const int h = lv.H[lvl], w = lv.W[lvl], wq = qt.wq[lvl];
+    while (lvl + 1 < lv.n && (int)blockIdx.x >= bt.first_blk[lvl + 1]) ++lvl;
+    int64_t q = (int64_t)((int)blockIdx.x - bt.first_blk[lvl]) * 64 + lq;
+    const bool active = q < bt.quads[lvl];
+    if (!active) q = 0;                       // idle lanes follow along on quad 0 and never store
+    const int h = lv.H[lvl], w = lv.W[lvl], wq = bt.wq[lvl];
     const int hr = lv.H[lv.r], wr = lv.W[lv.r];
     const int x0 = (int)(q % wq) * 4;
     const int y = (int)((q / wq) % h);
-    const int64_t bc = q / ((int64_t)wq * h);
-    const int c = (int)(bc % lv.C), bi = (int)(bc / lv.C);
-    const int64_t off = (bc * h + y) * (int64_t)w + x0;
+    const int bi = (int)(q / ((int64_t)wq * h));
+    const bool full = x0 + 3 < w;
 
-    float r[4];
+    // channel-independent neighbourhood of the two maps
+    float va[3][6], vb[3][6];
     {
-        const float* gp = gout.p[lvl] + off;
-        if (x0 + 3 < w) {
-            float4_u gv = *reinterpret_cast<const float4_u*>(gp);
-            r[0] = gv[0]; r[1] = gv[1]; r[2] = gv[2]; r[3] = gv[3];
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) r[e] = x0 + e < w ? gp[e] : 0.f;
-        }
-    }
-    // transposed 3x3 conv of the two 1-channel maps: dx[y,x] += sum_{ky,kx} W[c,ky,kx] * d[y-(ky-1), x-(kx-1)]
-    {
-        const float* k1 = w1.p[lvl] + c * 9;
-        const float* k2 = w2.p[lvl] + c * 9;
         const float* da = dpa.p[lvl] + (int64_t)bi * h * w;
         const float* db = dpb.p[lvl] + (int64_t)bi * h * w;
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             const int yy = y - (ky - 1);
-            if (yy < 0 || yy >= h) continue;
-            float va[6], vb[6];
+            const bool rok = yy >= 0 && yy < h;
 #pragma unroll
             for (int t = 0; t < 6; ++t) {
                 const int xx = x0 - 1 + t;
-                const bool ok = xx >= 0 && xx < w;
-                va[t] = ok ? da[(int64_t)yy * w + xx] : 0.f;
-                vb[t] = ok ? db[(int64_t)yy * w + xx] : 0.f;
+                const bool ok = rok && xx >= 0 && xx < w;
+                va[ky][t] = ok ? da[(int64_t)yy * w + xx] : 0.f;
+                vb[ky][t] = ok ? db[(int64_t)yy * w + xx] : 0.f;
             }
+        }
+    }
+    const float nlev = (float)lv.n;
+    const int64_t plane = (int64_t)h * w, plane_r = (int64_t)hr * wr;
+    const int sh = lv.sh[lvl];
+    // conv weights of this block's 4*IB_CG channels -> LDS (the compiler cannot prove the weight tensors are not
+    // aliased by the dx stores, so direct reads would be per-lane vector loads: 18 per channel and thread)
+    __shared__ float wsm[2][4 * IB_CG][9];
+    {
+        const int cb = blockIdx.y * 4 * IB_CG;
+        for (int i = threadIdx.x; i < 2 * 4 * IB_CG * 9; i += 256) {
+            const int which = i / (4 * IB_CG * 9), rem = i - which * (4 * IB_CG * 9);
+            const int cl = rem / 9;
+            const float* src = which ? w2.p[lvl] : w1.p[lvl];
+            (&wsm[0][0][0])[i] = cb + cl < lv.C ? src[(cb + cl) * 9 + (rem - cl * 9)] : 0.f;
+        }
+    }
+    // wave cw of block row blockIdx.y owns IB_CG consecutive channels; the loop is fully unrolled so that the
+    // global reads of all of them are in flight together
+    const int c_first = (blockIdx.y * 4 + cw) * IB_CG;
+    __syncthreads();
+    constexpr int UNR = POW2 ? IB_CG : 1;      // the generic-index variant stays a rolled loop (code size)
+#pragma unroll UNR
+    for (int cj = 0; cj < IB_CG; ++cj) {
+        const int c = c_first + cj;
+        if (c >= lv.C) break;
+        const int64_t bc = (int64_t)bi * lv.C + c;
+        const int64_t off = (bc * h + y) * (int64_t)w + x0;
+        float r[4];
+        {
+            const float* gp = gout.p[lvl] + off;
+            if (full) {
+                const float4_u gv = *reinterpret_cast<const float4_u*>(gp);
+                r[0] = gv[0]; r[1] = gv[1]; r[2] = gv[2]; r[3] = gv[3];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[e] = x0 + e < w ? gp[e] : 0.f;
+            }
+        }
+        const float* k1 = &wsm[0][cw * IB_CG + cj][0];
+        const float* k2 = &wsm[1][cw * IB_CG + cj][0];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 const float u = k1[ky * 3 + kx], s = k2[ky * 3 + kx];
-                // source column = x - (kx-1)  ->  window index (e + 1) - (kx - 1) = e + 2 - kx
+                // dx[y,x] += W[c,ky,kx] * d[y-(ky-1), x-(kx-1)] ; neighbourhood column index = e + 2 - kx
 #pragma unroll
-                for (int e = 0; e < 4; ++e) r[e] += u * va[e + 2 - kx] + s * vb[e + 2 - kx];
+                for (int e = 0; e < 4; ++e) r[e] += u * va[ky][e + 2 - kx] + s * vb[ky][e + 2 - kx];
             }
-        }
-    }
-    // gather^T
-    const float nlev = (float)lv.n;
-    const int64_t plane_r = (int64_t)hr * wr;
-    const float* dmp = dm + bc * plane_r;
-    const int sh = lv.sh[lvl];
-    if (lvl < lv.r) {
-        const int32_t* am = argmax + (int64_t)lvl * lv.B * lv.C * plane_r + bc * plane_r;
-        if (sh != SH_GENERAL && sh >= 0) {          // windows are the disjoint (1<<sh)^2 blocks: exactly one candidate
-            const int oy = y >> sh;
+        // gather^T
+        const float* dmp = dm + bc * plane_r;
+        if (lvl < lv.r) {
+            const int32_t* am = argmax + (int64_t)lvl * lv.B * lv.C * plane_r + bc * plane_r;
+            if (POW2 || (sh != SH_GENERAL && sh >= 0)) {
+                // windows are the disjoint (1<<sh)^2 blocks: one candidate per pixel; branch-free so that the index
+                // and value reads of all pixels/channels are issued together instead of serialised behind compares
+                const int oy = y >> sh;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int xx = x0 + e;
-                if (xx >= w) break;
-                const int64_t o = (int64_t)oy * wr + (xx >> sh);
-                if (am[o] == y * w + xx) r[e] += dmp[o] / nlev;
-            }
-        } else {
-            const int oy0 = (int)(((int64_t)y * hr) / h) - 1;
-            for (int e = 0; e < 4; ++e) {
-                const int xx = x0 + e;
-                if (xx >= w) break;
-                const int ox0 = (int)(((int64_t)xx * wr) / w) - 1;
-                const int flat = y * w + xx;
-                for (int oy = oy0; oy <= oy0 + 2; ++oy) {
-                    if (oy < 0 || oy >= hr) continue;
-                    if (y < pool_start(oy, h, hr) || y >= pool_end(oy, h, hr)) continue;
-                    for (int ox = ox0; ox <= ox0 + 2; ++ox) {
-                        if (ox < 0 || ox >= wr) continue;
-                        if (xx < pool_start(ox, w, wr) || xx >= pool_end(ox, w, wr)) continue;
-                        if (am[(int64_t)oy * wr + ox] == flat) r[e] += dmp[(int64_t)oy * wr + ox] / nlev;
+                for (int e = 0; e < 4; ++e) {
+                    const int xx = x0 + e < w ? x0 + e : w - 1;
+                    const int64_t o = (int64_t)oy * wr + (xx >> sh);
+                    const int idx = am[o];
+                    const float dv = dmp[o] / nlev;
+                    r[e] += (idx == y * w + xx && x0 + e < w) ? dv : 0.f;
+                }
+            } else if (!POW2) {
+                const int oy0 = (int)(((int64_t)y * hr) / h) - 1;
+                for (int e = 0; e < 4; ++e) {
+                    const int xx = x0 + e;
+                    if (xx >= w) break;
+                    const int ox0 = (int)(((int64_t)xx * wr) / w) - 1;
+                    const int flat = y * w + xx;
+                    for (int oy = oy0; oy <= oy0 + 2; ++oy) {
+                        if (oy < 0 || oy >= hr) continue;
+                        if (y < pool_start(oy, h, hr) || y >= pool_end(oy, h, hr)) continue;
+                        for (int ox = ox0; ox <= ox0 + 2; ++ox) {
+                            if (ox < 0 || ox >= wr) continue;
+                            if (xx < pool_start(ox, w, wr) || xx >= pool_end(ox, w, wr)) continue;
+                            if (am[(int64_t)oy * wr + ox] == flat) r[e] += dmp[(int64_t)oy * wr + ox] / nlev;
+                        }
                     }
                 }
             }
-        }
-    } else if (sh != SH_GENERAL) {                   // coarser (or same) level: refine block [y<<f, (y+1)<<f)
-        const int f = -sh, n = 1 << f;
+        } else if (POW2 || sh != SH_GENERAL) {
+            const int f = -sh, n = 1 << f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int xx = x0 + e;
-            if (xx >= w) break;
-            float s = 0.f;
-            for (int py = y << f; py < (y << f) + n; ++py)
-                for (int px = xx << f; px < (xx << f) + n; ++px) s += dmp[(int64_t)py * wr + px] / nlev;
-            r[e] += s;
+            for (int e = 0; e < 4; ++e) {
+                const int xx = x0 + e < w ? x0 + e : w - 1;
+                float s = 0.f;
+                for (int py = y << f; py < (y << f) + n; ++py)
+                    for (int px = xx << f; px < (xx << f) + n; ++px) s += dmp[(int64_t)py * wr + px] / nlev;
+                r[e] += s;
+            }
+        } else if (!POW2) {
+            const float ys = nearest_scale(h, hr), xs = nearest_scale(w, wr);
+            const int py0 = nearest_dst_begin(y, h, hr, ys), py1 = nearest_dst_begin(y + 1, h, hr, ys);
+            for (int e = 0; e < 4; ++e) {
+                const int xx = x0 + e;
+                if (xx >= w) break;
+                const int px0 = nearest_dst_begin(xx, w, wr, xs), px1 = nearest_dst_begin(xx + 1, w, wr, xs);
+                float s = 0.f;
+                for (int py = py0; py < py1; ++py)
+                    for (int px = px0; px < px1; ++px) s += dmp[(int64_t)py * wr + px] / nlev;
+                r[e] += s;
+            }
         }
-    } else {
-        const float ys = nearest_scale(h, hr), xs = nearest_scale(w, wr);
-        const int py0 = nearest_dst_begin(y, h, hr, ys), py1 = nearest_dst_begin(y + 1, h, hr, ys);
-        for (int e = 0; e < 4; ++e) {
-            const int xx = x0 + e;
-            if (xx >= w) break;
-            const int px0 = nearest_dst_begin(xx, w, wr, xs), px1 = nearest_dst_begin(xx + 1, w, wr, xs);
-            float s = 0.f;
-            for (int py = py0; py < py1; ++py)
-                for (int px = px0; px < px1; ++px) s += dmp[(int64_t)py * wr + px] / nlev;
-            r[e] += s;
+        float* op = dx.p[lvl] + off;
+        if (active) {
+            if (full) {
+                float4_u o = {r[0], r[1], r[2], r[3]};
+                *reinterpret_cast<float4_u*>(op) = o;
+            } else {
+                for (int e = 0; e < 4 && x0 + e < w; ++e) op[e] = r[e];
+            }
         }
     }
-    float* op = dx.p[lvl] + off;
-    if (x0 + 3 < w) {
-        float4_u o = {r[0], r[1], r[2], r[3]};
-        *reinterpret_cast<float4_u*>(op) = o;
-    } else {
-        for (int e = 0; e < 4 && x0 + e < w; ++e) op[e] = r[e];
-    }
+    (void)plane;
 }
 
 // =========================================================================================================
@@ -470,21 +521,34 @@ __global__ __launch_bounds__(256) void fpn_input_bwd_kernel(Levels lv, QuadTable
 //   scalars each, the row above/below come from L1/L2) and two 16-B map reads feed 72 FMAs; the 18 (+2 bias)
 //   accumulators are reduced once per workgroup, so results are written without atomics.
 // =========================================================================================================
+constexpr int WG_ZSPLIT = 8;       // row slices per image plane (more workgroups in flight; partial sums add atomically)
+__global__ void fpn_gate_wgrad_zero_kernel(int C, int n, LevelMutPtrs dw1, LevelMutPtrs db1, LevelMutPtrs dw2, LevelMutPtrs db2) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int per = 9 * C;
+    if (i < n * per) { const int l = i / per, j = i - l * per; dw1.p[l][j] = 0.f; dw2.p[l][j] = 0.f; }
+    if (i < n) { db1.p[i][0] = 0.f; db2.p[i][0] = 0.f; }
+}
 __global__ __launch_bounds__(256) void fpn_gate_wgrad_kernel(Levels lv, LevelPtrs x, LevelPtrs dpa, LevelPtrs dpb,
                                                              LevelMutPtrs dw1, LevelMutPtrs db1, LevelMutPtrs dw2,
                                                              LevelMutPtrs db2) {
     const int c = blockIdx.x, lvl = blockIdx.y;
     const int h = lv.H[lvl], w = lv.W[lvl], wq = (w + 3) >> 2;
+    const int bi = blockIdx.z / WG_ZSPLIT, zs = blockIdx.z - bi * WG_ZSPLIT;
+    const int rows_per = (h + WG_ZSPLIT - 1) / WG_ZSPLIT;
+    const int y_begin = zs * rows_per;
+    const int y_end = y_begin + rows_per < h ? y_begin + rows_per : h;
+    if (y_begin >= y_end) return;
     float s1[9], s2[9], sa = 0.f, sb = 0.f;
 #pragma unroll
     for (int t = 0; t < 9; ++t) { s1[t] = 0.f; s2[t] = 0.f; }
-    const int nq = h * wq;
-    for (int bi = 0; bi < lv.B; ++bi) {
+    const int nq = (y_end - y_begin) * wq;
+    {
         const float* xp = x.p[lvl] + ((int64_t)bi * lv.C + c) * h * w;
         const float* da = dpa.p[lvl] + (int64_t)bi * h * w;
         const float* db = dpb.p[lvl] + (int64_t)bi * h * w;
         for (int q = threadIdx.x; q < nq; q += 256) {
-            const int y = q / wq, x0 = (q - y * wq) << 2;
+            const int yl = q / wq;
+            const int y = y_begin + yl, x0 = (q - yl * wq) << 2;
             float a4[4], b4[4];
             if (x0 + 3 < w) {
                 const float4_u av = *reinterpret_cast<const float4_u*>(da + (int64_t)y * w + x0);
@@ -540,9 +604,9 @@ __global__ __launch_bounds__(256) void fpn_gate_wgrad_kernel(Levels lv, LevelPtr
     if (threadIdx.x < 20) {
         const int t = threadIdx.x;
         const float v = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
-        if (t < 9) dw1.p[lvl][c * 9 + t] = v;
-        else if (t < 18) dw2.p[lvl][c * 9 + (t - 9)] = v;
-        else if (c == 0) (t == 18 ? db1.p[lvl] : db2.p[lvl])[0] = v;
+        if (t < 9) unsafeAtomicAdd(dw1.p[lvl] + c * 9 + t, v);
+        else if (t < 18) unsafeAtomicAdd(dw2.p[lvl] + c * 9 + (t - 9), v);
+        else if (c == 0) unsafeAtomicAdd(t == 18 ? db1.p[lvl] : db2.p[lvl], v);
     }
 }
 
@@ -707,10 +771,29 @@ extern "C" int32_t arfe_fpn_input_bwd(const arfe_pyramid_t* pyr, const float* co
                        fill_ptrs(w1p, w1, lv.n) && fill_ptrs(w2p, w2, lv.n) && fill_ptrs(dxp, dx, lv.n) && dm &&
                        (argmax || lv.r == 0),
                    ARFE_ERR_ARG, "fpn_input_bwd: null pointer");
-    QuadTable qt = make_quad_table(lv);
-    hipLaunchKernelGGL(fpn_input_bwd_kernel, dim3((unsigned)cdiv64(qt.first[lv.n], 256)), dim3(256), 0, as_stream(stream),
-                       lv, qt, gp, dap, dbp, w1p, w2p, dm, argmax, dxp);
-    ARFE_CHECK_LAUNCH();
+    // levels with an exact power-of-two ratio to the refine level take the shift-only kernel, the rest (e.g. the
+    // 13x21 top level of the 1333x800 pyramid, 25 -> 13 by a ceil) the generic one: two launches over disjoint levels
+    for (int pass = 0; pass < 2; ++pass) {
+        BlockQuadTable bt;
+        int nblk = 0;
+        for (int i = 0; i <= NL_; ++i) {
+            bt.first_blk[i] = nblk;
+            if (i < NL_) {
+                const bool mine = i < lv.n && ((lv.sh[i] != SH_GENERAL) == (pass == 0));
+                bt.wq[i] = i < lv.n ? cdiv(lv.W[i], 4) : 0;
+                bt.quads[i] = mine ? (int64_t)lv.B * lv.H[i] * bt.wq[i] : 0;
+                nblk += (int)cdiv64(bt.quads[i], 64);
+            }
+        }
+        if (nblk == 0) continue;
+        if (pass == 0)
+            hipLaunchKernelGGL((fpn_input_bwd_kernel<true>), dim3(nblk, cdiv(lv.C, 4 * IB_CG)), dim3(256), 0,
+                               as_stream(stream), lv, bt, gp, dap, dbp, w1p, w2p, dm, argmax, dxp);
+        else
+            hipLaunchKernelGGL((fpn_input_bwd_kernel<false>), dim3(nblk, cdiv(lv.C, 4 * IB_CG)), dim3(256), 0,
+                               as_stream(stream), lv, bt, gp, dap, dbp, w1p, w2p, dm, argmax, dxp);
+        ARFE_CHECK_LAUNCH();
+    }
     return ARFE_OK;
 }
 
@@ -726,8 +809,11 @@ extern "C" int32_t arfe_fpn_gate_wgrad(const arfe_pyramid_t* pyr, const float* c
                        fill_ptrs(w1p, dw1, lv.n) && fill_ptrs(b1p, db1, lv.n) && fill_ptrs(w2p, dw2, lv.n) &&
                        fill_ptrs(b2p, db2, lv.n),
                    ARFE_ERR_ARG, "fpn_gate_wgrad: null pointer");
-    hipLaunchKernelGGL(fpn_gate_wgrad_kernel, dim3(lv.C, lv.n), dim3(256), 0, as_stream(stream), lv, xp, dap, dbp, w1p, b1p,
-                       w2p, b2p);
+    hipLaunchKernelGGL(fpn_gate_wgrad_zero_kernel, dim3(cdiv(lv.n * 9 * lv.C, 256)), dim3(256), 0, as_stream(stream), lv.C,
+                       lv.n, w1p, b1p, w2p, b2p);
+    ARFE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(fpn_gate_wgrad_kernel, dim3(lv.C, lv.n, lv.B * WG_ZSPLIT), dim3(256), 0, as_stream(stream), lv, xp,
+                       dap, dbp, w1p, b1p, w2p, b2p);
     ARFE_CHECK_LAUNCH();
     return ARFE_OK;
 }

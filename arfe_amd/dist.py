@@ -38,15 +38,20 @@ class GradBucket:
 
 
 class GradAllReducer:
-    """buckets: list of parameter lists, in the order their gradients become ready during backward."""
+    """buckets: list of parameter lists, in the order their gradients become ready during backward.
+    With a single process there is nothing to exchange: no buckets are created and autograd hands each
+    parameter its freshly produced gradient tensor (no accumulate-into-view pass)."""
 
     def __init__(self, param_groups):
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-        self.buckets = [GradBucket(list(g)) for g in param_groups]
-        self._pending = [0] * len(self.buckets)
-        for bi, b in enumerate(self.buckets):
-            for p in b.params:
-                p.register_post_accumulate_grad_hook(self._make_hook(bi))
+        self.param_groups = [[p for p in g if p.requires_grad] for g in param_groups]
+        self.buckets = []
+        if self.world > 1:
+            self.buckets = [GradBucket(list(g)) for g in self.param_groups]
+            self._pending = [0] * len(self.buckets)
+            for bi, b in enumerate(self.buckets):
+                for p in b.params:
+                    p.register_post_accumulate_grad_hook(self._make_hook(bi))
 
     def _make_hook(self, bi):
         def hook(param):
@@ -56,6 +61,11 @@ class GradAllReducer:
         return hook
 
     def zero_grad(self):
+        if self.world == 1:
+            for g in self.param_groups:
+                for p in g:
+                    p.grad = None
+            return
         for bi, b in enumerate(self.buckets):
             b.zero()
             self._pending[bi] = len(b.params)

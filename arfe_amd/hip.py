@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libarfe_hip.so")
+LIB_PATH = os.environ.get("ARFE_LIB", os.path.join(_HERE, "libarfe_hip.so"))   # ARFE_LIB: development builds only
 MAX_LEVELS = 8
 ABI_VERSION = 1
 

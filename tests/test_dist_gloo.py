@@ -75,4 +75,4 @@ def test_single_process_is_a_noop_reduce():
     red.zero_grad()
     lin(torch.ones(1, 3)).sum().backward()
     red.synchronize()
-    assert torch.allclose(lin.weight.grad, torch.ones(2, 3)) and red.world == 1
+    assert torch.allclose(lin.weight.grad, torch.ones(2, 3)) and red.world == 1 and red.buckets == []
