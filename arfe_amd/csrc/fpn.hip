@@ -357,9 +357,10 @@ struct BlockQuadTable {       // pixel quads (B*h*ceil(w/4)) of each level, in w
     int64_t quads[NL_];
     int wq[NL_];
 };
-// POW2: every level is an exact power-of-two multiple/fraction of the refine level (the padded pyramid): only the
-// shift-based index paths are compiled in (the generic paths made the kernel 167 KB of code at 256 VGPRs).
-template <bool POW2>
+// Each index regime is its own instantiation so that only its paths are compiled in (all paths in one kernel made
+// 167 KB of code at 256 VGPRs): levels with an exact power-of-two ratio to the refine level use shifts only.
+// MODE 0 = POW2 (shift-only paths), 1 = generic level >= refine (nearest^T), 2 = generic level < refine (pool windows)
+template <int MODE>
 __global__ __launch_bounds__(256) void fpn_input_bwd_kernel(Levels lv, BlockQuadTable bt, LevelPtrs gout, LevelPtrs dpa,
                                                             LevelPtrs dpb, LevelPtrs w1, LevelPtrs w2,
                                                             const float* __restrict__ dm, const int32_t* __restrict__ argmax,
@@ -416,7 +417,8 @@ __global__ __launch_bounds__(256) void fpn_input_bwd_kernel(Levels lv, BlockQuad
     // global reads of all of them are in flight together
     const int c_first = (blockIdx.y * 4 + cw) * IB_CG;
     __syncthreads();
-    constexpr int UNR = POW2 ? IB_CG : 1;      // the generic-index variant stays a rolled loop (code size)
+    constexpr bool POW2 = MODE == 0;
+    constexpr int UNR = MODE == 2 ? 1 : IB_CG;  // the pool-window search variant stays a rolled loop (code size)
 #pragma unroll UNR
     for (int cj = 0; cj < IB_CG; ++cj) {
         const int c = c_first + cj;
@@ -447,7 +449,7 @@ __global__ __launch_bounds__(256) void fpn_input_bwd_kernel(Levels lv, BlockQuad
             }
         // gather^T
         const float* dmp = dm + bc * plane_r;
-        if (lvl < lv.r) {
+        if (MODE != 1 && lvl < lv.r) {
             const int32_t* am = argmax + (int64_t)lvl * lv.B * lv.C * plane_r + bc * plane_r;
             if (POW2 || (sh != SH_GENERAL && sh >= 0)) {
                 // windows are the disjoint (1<<sh)^2 blocks: one candidate per pixel; branch-free so that the index
@@ -461,7 +463,7 @@ __global__ __launch_bounds__(256) void fpn_input_bwd_kernel(Levels lv, BlockQuad
                     const float dv = dmp[o] / nlev;
                     r[e] += (idx == y * w + xx && x0 + e < w) ? dv : 0.f;
                 }
-            } else if (!POW2) {
+            } else if (MODE == 2) {
                 const int oy0 = (int)(((int64_t)y * hr) / h) - 1;
                 for (int e = 0; e < 4; ++e) {
                     const int xx = x0 + e;
@@ -489,7 +491,7 @@ __global__ __launch_bounds__(256) void fpn_input_bwd_kernel(Levels lv, BlockQuad
                     for (int px = xx << f; px < (xx << f) + n; ++px) s += dmp[(int64_t)py * wr + px] / nlev;
                 r[e] += s;
             }
-        } else if (!POW2) {
+        } else if (MODE == 1) {
             const float ys = nearest_scale(h, hr), xs = nearest_scale(w, wr);
             const int py0 = nearest_dst_begin(y, h, hr, ys), py1 = nearest_dst_begin(y + 1, h, hr, ys);
             for (int e = 0; e < 4; ++e) {
@@ -773,25 +775,29 @@ extern "C" int32_t arfe_fpn_input_bwd(const arfe_pyramid_t* pyr, const float* co
                    ARFE_ERR_ARG, "fpn_input_bwd: null pointer");
     // levels with an exact power-of-two ratio to the refine level take the shift-only kernel, the rest (e.g. the
     // 13x21 top level of the 1333x800 pyramid, 25 -> 13 by a ceil) the generic one: two launches over disjoint levels
-    for (int pass = 0; pass < 2; ++pass) {
+    for (int pass = 0; pass < 3; ++pass) {
         BlockQuadTable bt;
         int nblk = 0;
         for (int i = 0; i <= NL_; ++i) {
             bt.first_blk[i] = nblk;
             if (i < NL_) {
-                const bool mine = i < lv.n && ((lv.sh[i] != SH_GENERAL) == (pass == 0));
+                const int mode = i >= lv.n ? -1 : (lv.sh[i] != SH_GENERAL ? 0 : (i >= lv.r ? 1 : 2));
                 bt.wq[i] = i < lv.n ? cdiv(lv.W[i], 4) : 0;
-                bt.quads[i] = mine ? (int64_t)lv.B * lv.H[i] * bt.wq[i] : 0;
+                bt.quads[i] = mode == pass ? (int64_t)lv.B * lv.H[i] * bt.wq[i] : 0;
                 nblk += (int)cdiv64(bt.quads[i], 64);
             }
         }
         if (nblk == 0) continue;
+        const dim3 grid(nblk, cdiv(lv.C, 4 * IB_CG));
         if (pass == 0)
-            hipLaunchKernelGGL((fpn_input_bwd_kernel<true>), dim3(nblk, cdiv(lv.C, 4 * IB_CG)), dim3(256), 0,
-                               as_stream(stream), lv, bt, gp, dap, dbp, w1p, w2p, dm, argmax, dxp);
+            hipLaunchKernelGGL((fpn_input_bwd_kernel<0>), grid, dim3(256), 0, as_stream(stream), lv, bt, gp, dap, dbp, w1p,
+                               w2p, dm, argmax, dxp);
+        else if (pass == 1)
+            hipLaunchKernelGGL((fpn_input_bwd_kernel<1>), grid, dim3(256), 0, as_stream(stream), lv, bt, gp, dap, dbp, w1p,
+                               w2p, dm, argmax, dxp);
         else
-            hipLaunchKernelGGL((fpn_input_bwd_kernel<false>), dim3(nblk, cdiv(lv.C, 4 * IB_CG)), dim3(256), 0,
-                               as_stream(stream), lv, bt, gp, dap, dbp, w1p, w2p, dm, argmax, dxp);
+            hipLaunchKernelGGL((fpn_input_bwd_kernel<2>), grid, dim3(256), 0, as_stream(stream), lv, bt, gp, dap, dbp, w1p,
+                               w2p, dm, argmax, dxp);
         ARFE_CHECK_LAUNCH();
     }
     return ARFE_OK;

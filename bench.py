@@ -28,6 +28,23 @@ PEAK_HBM_GBS = 8000.0            # spec; ~6300 GB/s achievable by a float4 copy
 ARFPN_HBM_BYTES_PER_IMG = 458.4e6   # fwd 2 x 91.67 MB + bwd 3 x 91.67 MB
 
 
+def pmc_traffic(kernel_substr):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE doubled as
+    the gfx950 note in MI355X_MICROARCH.md prescribes, + WRITE_SIZE; tools/pmc_run.sh + tools/pmc_traffic.py on this
+    same bench command).  None when the profile file is absent."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_traffic.json')
+    if not os.path.exists(path):
+        return None
+    try:
+        d = json.load(open(path))
+        for k, v in d.items():
+            if all(t in k for t in kernel_substr):
+                return v["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+    return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -180,11 +197,15 @@ def main():
                        "per_gpu_batch": B, "global_batch": world * B, "rois_per_gpu": R, "channels": 256,
                        "pyramid": "200x336,100x168,50x84,25x42,13x21", "parallelism": f"image-dp{world}"},
             "roofline": {"bound": "mfma",
-                         "kernel": ("gemm_f32_kernel" if f32_mode else "gemm_bf16x3_kernel") +
+                         "kernel": ("gemm_f32_kernel" if f32_mode else "gemm_bf16x3_large_kernel") +
                                    "<LoadRowMajorK,ConvGatherB,EpiConv> (3x3 conv 256->256 on [R,256,7,7], fwd + data-grad)",
                          "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(ach / peak, 4), "traffic": None,
+                         "frac": round(ach / peak, 4),
+                         "traffic": None if f32_mode else pmc_traffic(("gemm_bf16x3_large_kernel", "ConvGatherB")),
+                         "traffic_unit": "bytes/launch (PMC, profiles/r01_pmc_hbm_traffic.json)",
+                         "algorithmic_bytes_per_launch": int(2 * R * 256 * 49 * 4 + 9 * 256 * 256 * 4),
                          "mfma_flop_per_algorithmic_flop": 1 if f32_mode else 3,
+                         "frac_of_exact_fp32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
                          "flop_per_launch": conv_flop, "avg_launch_ms": round(avg_ms, 4), "launches": len(conv_ms)},
             "roofline_hbm_stages": {"bound": "hbm", "stages": "AR-FPN gather+gate+scatter fwd/bwd (NonLocal excluded)",
                                     "achieved": round(hbm_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
