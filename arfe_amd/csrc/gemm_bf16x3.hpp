@@ -295,13 +295,33 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_large_kernel(GemmDims d, L
         if (s_begin + 1 < s_end) fetch(s_begin + 1);
         __syncthreads();
         int buf = 0;
-        for (int s = s_begin; s < s_end; ++s) {
-            const bool more = s + 1 < s_end;
-            // program order interleaves the VALU-heavy split/store of the next step with the two MFMA halves
-            if (more) stash_a(buf ^ 1);
+        int s = s_begin;
+        // steady state (branch-free body = one scheduling region): the split+store of step s+1 and the global loads of
+        // step s+2 are interleaved with the 48 MFMAs of step s by the scheduler directives below
+        for (; s + 2 < s_end; ++s) {
+            stash_a(buf ^ 1);
             mma(buf, 0);
-            if (more) stash_b(buf ^ 1);
-            if (s + 2 < s_end) fetch(s + 2);
+            stash_b(buf ^ 1);
+            fetch(s + 2);
+            mma(buf, 16);
+#if !defined(ARFE_NO_SCHED_GROUPS)
+            // per MFMA: a few VALU (operand split), then LDS / global traffic spread over the MFMA stream
+#pragma unroll
+            for (int g = 0; g < 48; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // 4 VALU
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+                if (g % 3 == 0) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
+                if (g % 2 == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+            }
+#endif
+            __syncthreads();
+            buf ^= 1;
+        }
+        for (; s < s_end; ++s) {       // last two steps: nothing left to fetch / stash
+            const bool more = s + 1 < s_end;
+            if (more) { stash_a(buf ^ 1); stash_b(buf ^ 1); }
+            mma(buf, 0);
             mma(buf, 16);
             __syncthreads();
             buf ^= 1;

@@ -80,6 +80,25 @@ struct WgradA {        // A(m=co, k') = dy[r*roi_stride + co*49 + p]
         for (int j = 1; j < 8; ++j) v[j] = (ok && oc < 6) ? t[j] : 0.f;
     }
 };
+// validity of the 8 pixels of octet oc (p = 8*oc + j) under tap t: bit j set when (py+dy, px+dx) is inside the 7x7 tile
+struct WgradMask { unsigned char m[9][7]; };
+constexpr WgradMask make_wgrad_mask() {
+    WgradMask w{};
+    for (int t = 0; t < 9; ++t)
+        for (int oc = 0; oc < 7; ++oc) {
+            unsigned b = 0;
+            for (int j = 0; j < 8; ++j) {
+                const int p = oc * 8 + j;
+                if (p >= 49) continue;
+                const int yy = p / 7 + t / 3 - 1, xx = p % 7 + t % 3 - 1;
+                if (yy >= 0 && yy < 7 && xx >= 0 && xx < 7) b |= 1u << j;
+            }
+            w.m[t][oc] = (unsigned char)b;
+        }
+    return w;
+}
+__constant__ WgradMask WGRAD_MASK = make_wgrad_mask();
+
 struct WgradB {        // B(n=ci, k') for tap z: x[r*roi_stride + ci*49 + shift(p, tap)]
     const float* x; int64_t roi_stride; int Cin, R;
     static constexpr bool kfast = true;
@@ -91,22 +110,31 @@ struct WgradB {        // B(n=ci, k') for tap z: x[r*roi_stride + ci*49 + shift(
         if ((unsigned)yy >= 7u || (unsigned)xx >= 7u) return 0.f;
         return x[(int64_t)r * roi_stride + n * 49 + yy * 7 + xx];
     }
-    struct Row { const float* q; bool ok; };
-    __device__ __forceinline__ Row row(int, int n) const { return Row{x + (n < Cin ? n : Cin - 1) * 49, n < Cin}; }
+    struct Row { int n; bool ok; };
+    __device__ __forceinline__ Row row(int, int n) const { return Row{n < Cin ? n : Cin - 1, n < Cin}; }
     template <bool FULLK>
     __device__ __forceinline__ void load8(const Row& r, int z, int, int k0, float (&v)[8]) const {
-        const int o8 = k0 >> 3, ri = o8 / 7, oc = o8 - ri * 7;
-        const bool ok = r.ok && ri < R;
-        const float* q = r.q + (int64_t)(ri < R ? ri : R - 1) * roi_stride;
-        const int dyo = z / 3 - 1, dxo = z % 3 - 1;
-        int py = (oc * 8) / 7, px = oc * 8 - py * 7;
+        const int o8 = k0 >> 3, ri0 = o8 / 7, oc = o8 - ri0 * 7;
+        const bool ok = r.ok && ri0 < R;
+        const int ri = ri0 < R ? ri0 : R - 1;
+        const int off = (z / 3 - 1) * 7 + (z % 3 - 1);
+        // a valid pixel p reads source p + off, so the octet is ONE contiguous 8-float window starting at 8*oc + off;
+        // pixels whose source would fall outside the channel's 49 floats are exactly the masked ones, so the window
+        // may overhang into the neighbouring channel as long as it stays inside the tensor slice
+        const int64_t start = (int64_t)ri * roi_stride + r.n * 49 + oc * 8 + off;
+        const int64_t last = (int64_t)(R - 1) * roi_stride + (int64_t)Cin * 49 - 8;
+        const unsigned mask = ok ? WGRAD_MASK.m[z][oc] : 0u;
+        if (start >= 0 && start <= last) {
+            ld8_contig(x + start, v);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int yy = py + dyo, xx = px + dxo;
-            const bool in = ok && oc * 8 + j < 49 && (unsigned)yy < 7u && (unsigned)xx < 7u;
-            const float t = q[in ? yy * 7 + xx : 0];
-            v[j] = in ? t : 0.f;
-            if (++px == 7) { px = 0; ++py; }
+            for (int j = 0; j < 8; ++j) v[j] = (mask >> j) & 1u ? v[j] : 0.f;
+        } else {                          // first / last few floats of the slice: element-wise, clamped
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int64_t a = start + j;
+                const float t = x[a < 0 ? 0 : (a > last + 7 ? last + 7 : a)];
+                v[j] = (mask >> j) & 1u ? t : 0.f;
+            }
         }
     }
 };

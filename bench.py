@@ -113,15 +113,20 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    # one rank per GPU; ARFE_DIST_BACKEND=gloo lets several ranks share one GPU to rehearse the N>1 code path
+    backend = os.environ.get('ARFE_DIST_BACKEND', 'nccl')
+    dev_index = local_rank if backend == 'nccl' else local_rank % torch.cuda.device_count()
+    dev = torch.device('cuda', dev_index)
+    torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+        if backend == 'nccl':
+            dist.init_process_group(backend='nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    dev = torch.device('cuda', local_rank)
-    torch.cuda.set_device(dev)
 
     from arfe_amd import functional as Fn
     from arfe_amd.dist import GradAllReducer
