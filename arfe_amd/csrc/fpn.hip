@@ -403,11 +403,12 @@ __global__ __launch_bounds__(256) void fpn_input_bwd_kernel(Levels lv, BlockQuad
     const int sh = lv.sh[lvl];
     // conv weights of this block's 4*IB_CG channels -> LDS (the compiler cannot prove the weight tensors are not
     // aliased by the dx stores, so direct reads would be per-lane vector loads: 18 per channel and thread)
-    __shared__ float wsm[2][4 * IB_CG][9];
+    constexpr int CG = MODE == 0 ? IB_CG : 1;   // generic-index levels are tiny: one channel per wave, more workgroups
+    __shared__ float wsm[2][4 * CG][9];
     {
-        const int cb = blockIdx.y * 4 * IB_CG;
-        for (int i = threadIdx.x; i < 2 * 4 * IB_CG * 9; i += 256) {
-            const int which = i / (4 * IB_CG * 9), rem = i - which * (4 * IB_CG * 9);
+        const int cb = blockIdx.y * 4 * CG;
+        for (int i = threadIdx.x; i < 2 * 4 * CG * 9; i += 256) {
+            const int which = i / (4 * CG * 9), rem = i - which * (4 * CG * 9);
             const int cl = rem / 9;
             const float* src = which ? w2.p[lvl] : w1.p[lvl];
             (&wsm[0][0][0])[i] = cb + cl < lv.C ? src[(cb + cl) * 9 + (rem - cl * 9)] : 0.f;
@@ -415,12 +416,11 @@ __global__ __launch_bounds__(256) void fpn_input_bwd_kernel(Levels lv, BlockQuad
     }
     // wave cw of block row blockIdx.y owns IB_CG consecutive channels; the loop is fully unrolled so that the
     // global reads of all of them are in flight together
-    const int c_first = (blockIdx.y * 4 + cw) * IB_CG;
+    const int c_first = (blockIdx.y * 4 + cw) * CG;
     __syncthreads();
     constexpr bool POW2 = MODE == 0;
-    constexpr int UNR = MODE == 2 ? 1 : IB_CG;  // the pool-window search variant stays a rolled loop (code size)
-#pragma unroll UNR
-    for (int cj = 0; cj < IB_CG; ++cj) {
+#pragma unroll
+    for (int cj = 0; cj < CG; ++cj) {
         const int c = c_first + cj;
         if (c >= lv.C) break;
         const int64_t bc = (int64_t)bi * lv.C + c;
@@ -436,8 +436,8 @@ __global__ __launch_bounds__(256) void fpn_input_bwd_kernel(Levels lv, BlockQuad
                 for (int e = 0; e < 4; ++e) r[e] = x0 + e < w ? gp[e] : 0.f;
             }
         }
-        const float* k1 = &wsm[0][cw * IB_CG + cj][0];
-        const float* k2 = &wsm[1][cw * IB_CG + cj][0];
+        const float* k1 = &wsm[0][cw * CG + cj][0];
+        const float* k2 = &wsm[1][cw * CG + cj][0];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -788,7 +788,7 @@ extern "C" int32_t arfe_fpn_input_bwd(const arfe_pyramid_t* pyr, const float* co
             }
         }
         if (nblk == 0) continue;
-        const dim3 grid(nblk, cdiv(lv.C, 4 * IB_CG));
+        const dim3 grid(nblk, cdiv(lv.C, 4 * (pass == 0 ? IB_CG : 1)));
         if (pass == 0)
             hipLaunchKernelGGL((fpn_input_bwd_kernel<0>), grid, dim3(256), 0, as_stream(stream), lv, bt, gp, dap, dbp, w1p,
                                w2p, dm, argmax, dxp);

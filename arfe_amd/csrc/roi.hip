@@ -400,36 +400,65 @@ __global__ __launch_bounds__(256) void roialign_bwd_tiles_kernel(RoiLevels L, Ro
     const int beg = lbeg + seg * per_seg;
     const int end = beg + per_seg < lend ? beg + per_seg : lend;
     const int grp = tid >> 4;                  // phase C role: channel c0+grp, all 7 bin rows, column px
+    // phase A/B roles: thread t < 112 -> weight of (tile row t/7, bin t%7); 128 <= t < 240 -> (tile column, bin);
+    // every thread copies up to RB_GPT floats of each RoI's 16x49 gradient block
+    const bool a_role = tid < RT * 7 || (tid >= 128 && tid < 128 + RT * 7);
+    const int a_axis = tid >> 7, a_u = tid & 127, a_r = a_u / 7, a_pb = a_u - a_r * 7;
+    constexpr int RB_GPT = (RB_CC * 49 + 255) / 256;      // 4
+    // register prefetch of one batch: the dependent global reads (list -> header -> table, gradients) of batch n+1
+    // are in flight while batch n is contracted
+    float pw[RB_NB], pg[RB_NB][RB_GPT];
+    auto prefetch = [&](int e0) {
+        const int nb = end - e0 < RB_NB ? end - e0 : RB_NB;
+#pragma unroll
+        for (int j = 0; j < RB_NB; ++j) {
+            pw[j] = 0.f;
+#pragma unroll
+            for (int i = 0; i < RB_GPT; ++i) pg[j][i] = 0.f;
+            if (j >= nb) continue;
+            const int id = list[e0 + j];
+            const int s = id / S.R, k = id - s * S.R;
+            if (a_role) {
+                const RoiWeightHdr* hp = hdr + id;
+                const int big = hp->big;
+                float w;
+                if (big == 0) {
+                    const int off = (a_axis ? tx * RT - hp->x0 : ty * RT - hp->y0) + a_r;
+                    w = (off >= 0 && off < RW_EXT) ? wtab[((int64_t)id * 2 + a_axis) * 7 * RW_EXT + a_pb * RW_EXT + off] : 0.f;
+                } else {
+                    const RoiGeom g = roi_geom(S.rois[s] + 5 * (int64_t)k, scale, P, sample_num);
+                    w = a_axis ? axis_weight(g.x_start, g.bin_w, g.grid_w, a_pb, W, tx * RT + a_r)
+                               : axis_weight(g.y_start, g.bin_h, g.grid_h, a_pb, H, ty * RT + a_r);
+                }
+                pw[j] = a_axis ? w : w * hp->inv;
+            }
+            const float* gp = gout + (int64_t)k * g_roi_stride + ((int64_t)s * L.C + c0) * 49;
+#pragma unroll
+            for (int i = 0; i < RB_GPT; ++i) {
+                const int q = tid + 256 * i;
+                if (q < ncc * 49) pg[j][i] = gp[q];
+            }
+        }
+    };
+    if (beg < end) prefetch(beg);
     for (int e0 = beg; e0 < end; e0 += RB_NB) {
         const int nb = end - e0 < RB_NB ? end - e0 : RB_NB;
         __syncthreads();                       // previous batch's LDS reads are done
-        for (int j = 0; j < nb; ++j) {
-            const int id = list[e0 + j];
-            const int s = id / S.R, k = id - s * S.R;
-            // ---- A: this tile's slice of the RoI's 1-D weight tables (threads 0..111 rows, 128..239 columns) ----
-            if (tid < RT * 7 || (tid >= 128 && tid < 128 + RT * 7)) {
-                const RoiWeightHdr* hp = hdr + id;
-                struct { int y0, x0, big; float inv; } h = {hp->y0, hp->x0, hp->big, hp->inv};
-                const int axis = tid >> 7, u = tid & 127, r = u / 7, pb = u - r * 7;
-                float w;
-                if (h.big == 0) {
-                    const int off = (axis ? tx * RT - h.x0 : ty * RT - h.y0) + r;
-                    w = (off >= 0 && off < RW_EXT) ? wtab[((int64_t)id * 2 + axis) * 7 * RW_EXT + pb * RW_EXT + off] : 0.f;
-                } else {
-                    const RoiGeom g = roi_geom(S.rois[s] + 5 * (int64_t)k, scale, P, sample_num);
-                    w = axis ? axis_weight(g.x_start, g.bin_w, g.grid_w, pb, W, tx * RT + r)
-                             : axis_weight(g.y_start, g.bin_h, g.grid_h, pb, H, ty * RT + r);
+        // ---- A/B: registers -> LDS ----
+#pragma unroll
+        for (int j = 0; j < RB_NB; ++j) {
+            if (a_role) { if (a_axis) wx_s[j][a_r][a_pb] = pw[j]; else wy_s[j][a_r][a_pb] = pw[j]; }
+#pragma unroll
+            for (int i = 0; i < RB_GPT; ++i) {
+                const int q = tid + 256 * i;
+                if (q < RB_CC * 49) {
+                    const int c = q / 49, r2 = q - c * 49, ph = r2 / 7;
+                    G_s[j][c][ph][r2 - ph * 7] = pg[j][i];
                 }
-                if (axis) wx_s[j][r][pb] = w; else wy_s[j][r][pb] = w * h.inv;
-            }
-            // ---- B: upstream gradients: ncc*49 contiguous floats ----
-            const float* gp = gout + (int64_t)k * g_roi_stride + ((int64_t)s * L.C + c0) * 49;
-            for (int i = tid; i < ncc * 49; i += 256) {
-                const int c = i / 49, q = i - c * 49, ph = q / 7;
-                G_s[j][c][ph][q - ph * 7] = gp[i];
             }
         }
         __syncthreads();
+        if (e0 + RB_NB < end) prefetch(e0 + RB_NB);
         // ---- C: column contraction T[ph][x][c] = sum_pw wx[x][pw] G[c][ph][pw] ----
         if (grp < ncc) {
             for (int j = 0; j < nb; ++j) {
@@ -440,7 +469,7 @@ __global__ __launch_bounds__(256) void roialign_bwd_tiles_kernel(RoiLevels L, Ro
                     const float4 g0 = *reinterpret_cast<const float4*>(&G_s[j][grp][ph][0]);
                     const float4 g1 = *reinterpret_cast<const float4*>(&G_s[j][grp][ph][4]);
                     T_s[j][ph][grp >> 2][px][grp & 3] = w0.x * g0.x + w0.y * g0.y + w0.z * g0.z + w0.w * g0.w + w1.x * g1.x +
-                                          w1.y * g1.y + w1.z * g1.z;
+                                                        w1.y * g1.y + w1.z * g1.z;
                 }
             }
         }
