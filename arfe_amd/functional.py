@@ -59,6 +59,33 @@ def _ws(nbytes, device):
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
 
+_side_stream = {}
+
+
+def side_stream(device):
+    """A second HIP stream per device for the parameter-gradient kernels: they depend only on the incoming gradient
+    and a saved activation, never on each other's results, so they run beside the data-gradient chain and fill the
+    CUs a 196-workgroup GEMM leaves idle (256 CUs)."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if key not in _side_stream:
+        _side_stream[key] = torch.cuda.Stream(device=device)
+    return _side_stream[key]
+
+
+
+def on_side(device, fn):
+    """Run fn() on the side stream, ordered after everything already enqueued on the current stream."""
+    main = torch.cuda.current_stream()
+    side = side_stream(device)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        return fn()
+
+
+def join_side(device):
+    torch.cuda.current_stream().wait_stream(side_stream(device))
+
+
 # ---------------------------------------------------------------------------------------------------------
 # AR-FPN raw ops
 # ---------------------------------------------------------------------------------------------------------
@@ -197,9 +224,13 @@ class ARFPNFunction(torch.autograd.Function):
         wt, bt, wp, bp, wg, bg, wo, bo = t[5 * n:5 * n + 8]
         w1, b1, w2, b2 = ([v.contiguous() for v in l] for l in (w1, b1, w2, b2))
         need_grad = any(ctx.needs_input_grad)
+        dev = xs[0].device
+        # the gate maps depend only on the inputs: they stream the pyramid on the side stream while the small
+        # NonLocal contractions (which cannot fill the chip) run on the main one
+        a, b = on_side(dev, lambda: fpn_gatemap_op(xs, w1, b1, w2, b2, refine_level))
         m, argmax = fpn_gather_op(xs, refine_level, want_argmax=need_grad)
         bsf, saved = nonlocal_fwd_op(m, wt, bt, wp, bp, wg, bg, wo, bo)
-        a, b = fpn_gatemap_op(xs, w1, b1, w2, b2, refine_level)
+        join_side(dev)
         outs = fpn_scatter_op(xs, bsf, a, b, refine_level)
         ctx.refine_level, ctx.n = refine_level, n
         if need_grad:
@@ -218,10 +249,12 @@ class ARFPNFunction(torch.autograd.Function):
         saved = s[5 * n + 6:5 * n + 9]
         argmax = s[5 * n + 9] if ctx.has_argmax else None
         gouts = [g.contiguous() if g is not None else torch.zeros_like(x) for g, x in zip(gouts, xs)]
+        dev = xs[0].device
         dpa, dpb, dbsf = fpn_scatter_bwd_op(gouts, bsf, a, b, r)
+        dw1, db1, dw2, db2 = on_side(dev, lambda: fpn_gate_wgrad_op(xs, dpa, dpb, r))   # beside the NonLocal backward
         dm, (dwt, dbt, dwp, dbp, dwg, dbg, dwo, dbo) = nonlocal_bwd_op(dbsf, m, wt, wp, wg, wo, saved)
         dxs = fpn_input_bwd_op(gouts, dpa, dpb, w1, w2, dm, argmax, r)
-        dw1, db1, dw2, db2 = fpn_gate_wgrad_op(xs, dpa, dpb, r)
+        join_side(dev)
         return (None, None, *dxs, *dw1, *db1, *dw2, *db2, dwt, dbt, dwp, dbp, dwg, dbg, dwo, dbo)
 
 
@@ -335,13 +368,16 @@ def conv3x3_fwd_op(x_view, roi_stride, R, C, packed, b, relu):
     return y
 
 
-def conv3x3_bwd_op(x_view, x_roi_stride, R, C, w, packed, dy, dx_view, dx_roi_stride, ws, dx_mask=0, dx_mask_stride=0):
-    """dy must already carry this conv's ReLU backward; dx is masked by dx_mask (the ReLU that fed this conv)."""
-    dw = torch.empty_like(w)
-    db = torch.empty(C, device=w.device)
+def conv3x3_bwd_data_op(R, C, packed, dy, dx_view, dx_roi_stride, dx_mask=0, dx_mask_stride=0):
+    """dx = conv^T(dy) (* [dx_mask > 0]); dy must already carry this conv's ReLU backward."""
     with probe('conv3x3_bwd_data'):
         check(hip.lib().arfe_conv3x3_bwd_data(R, C, ptr(packed), ptr(dy), C * 49, dx_view, dx_roi_stride, dx_mask,
                                               dx_mask_stride, stream()), "arfe_conv3x3_bwd_data")
+
+
+def conv3x3_bwd_weight_op(x_view, x_roi_stride, R, C, w, dy, ws):
+    dw = torch.empty_like(w)
+    db = torch.empty(C, device=w.device)
     with probe('conv3x3_bwd_weight'):
         check(hip.lib().arfe_conv3x3_bwd_weight(R, C, x_view, x_roi_stride, ptr(dy), C * 49, ptr(dw), ptr(db), ptr(ws),
                                                 stream()), "arfe_conv3x3_bwd_weight")
@@ -356,17 +392,23 @@ def linear_fwd_op(x, w, b, relu):
     return y
 
 
-def linear_bwd_op(x, w, dy, dx=None, accumulate_dx=False, mask_dx_by_x=False, need_dx=True):
-    """dy is used as is (ReLU backward is applied by the producer of dy: mask_dx_by_x of the later layer)."""
+def linear_bwd_data_op(x, w, dy, dx=None, accumulate_dx=False, mask_dx_by_x=False):
+    """dx = dy W (* [x > 0]); dy is used as is (ReLU backward is applied by the producer of dy)."""
     R, out_f, in_f = x.shape[0], w.shape[0], w.shape[1]
-    if need_dx and dx is None:
+    if dx is None:
         dx = torch.empty(R, in_f, device=x.device)
+    check(hip.lib().arfe_linear_bwd(R, in_f, out_f, ptr(x), ptr(w), ptr(dy), ptr(dx), int(accumulate_dx),
+                                    int(mask_dx_by_x), 0, 0, stream()), "arfe_linear_bwd")
+    return dx
+
+
+def linear_bwd_weight_op(x, w, dy):
+    R, out_f, in_f = x.shape[0], w.shape[0], w.shape[1]
     dw = torch.empty_like(w)
     db = torch.empty(out_f, device=x.device)
-    check(hip.lib().arfe_linear_bwd(R, in_f, out_f, ptr(x), ptr(w), ptr(dy), ptr(dx) if need_dx else 0,
-                                    int(accumulate_dx), int(mask_dx_by_x), ptr(dw), ptr(db), stream()),
+    check(hip.lib().arfe_linear_bwd(R, in_f, out_f, ptr(x), ptr(w), ptr(dy), 0, 0, 0, ptr(dw), ptr(db), stream()),
           "arfe_linear_bwd")
-    return dx, dw, db
+    return dw, db
 
 
 class RFFHeadFunction(torch.autograd.Function):
@@ -385,8 +427,10 @@ class RFFHeadFunction(torch.autograd.Function):
         pk_wh, pk_hh, pk_f = conv3x3_pack_op(w_wh), conv3x3_pack_op(w_hh), conv3x3_pack_op(w_f)
         rs = C3 * 49
         base = x.data_ptr()
+        # the two gating convs are independent: two 196-workgroup launches side by side pack the 256 CUs
+        lh = on_side(x.device, lambda: conv3x3_fwd_op(base + 4 * 2 * C * 49, rs, R, C, pk_hh, b_hh, True))
         lw = conv3x3_fwd_op(base + 4 * C * 49, rs, R, C, pk_wh, b_wh, True)
-        lh = conv3x3_fwd_op(base + 4 * 2 * C * 49, rs, R, C, pk_hh, b_hh, True)
+        join_side(x.device)
         z = torch.empty(R, C, 7, 7, device=x.device)
         check(hip.lib().arfe_rff_fuse_fwd(R, C, base, rs, ptr(lw), ptr(lh), ptr(z), stream()), "arfe_rff_fuse_fwd")
         z2 = conv3x3_fwd_op(z.data_ptr(), C * 49, R, C, pk_f, b_f, True)
@@ -407,21 +451,35 @@ class RFFHeadFunction(torch.autograd.Function):
         dcls = dcls.contiguous() if dcls is not None else torch.zeros(R, wc.shape[0], device=dev)
         dreg = dreg.contiguous() if dreg is not None else torch.zeros(R, wr.shape[0], device=dev)
         ws = _ws(hip.lib().arfe_conv3x3_workspace_bytes(C), dev)
-        # every ReLU backward is folded into the epilogue of the kernel that PRODUCES the gradient
-        df2, dwc, dbc = linear_bwd_op(f2, wc, dcls)
-        _, dwr, dbr = linear_bwd_op(f2, wr, dreg, dx=df2, accumulate_dx=True, mask_dx_by_x=True)   # df2 *= [f2>0]
-        df1, dw2, db2 = linear_bwd_op(f1, w2, df2, mask_dx_by_x=True)                             # df1 *= [f1>0]
+        # Every ReLU backward is folded into the epilogue of the kernel that PRODUCES the gradient.
+        # Data gradients form the critical chain on the current stream; each parameter gradient is launched on the
+        # side stream as soon as its incoming gradient exists.
         z2f = z2.view(R, -1)
-        dz2, dw1, db1 = linear_bwd_op(z2f, w1, df1, mask_dx_by_x=True)                            # dz2 *= [z2>0]
+
+        def side_do(fn):
+            return on_side(dev, fn)
+
+        dwc, dbc = side_do(lambda: linear_bwd_weight_op(f2, wc, dcls))
+        dwr, dbr = side_do(lambda: linear_bwd_weight_op(f2, wr, dreg))
+        df2 = linear_bwd_data_op(f2, wc, dcls)
+        linear_bwd_data_op(f2, wr, dreg, dx=df2, accumulate_dx=True, mask_dx_by_x=True)        # df2 *= [f2>0]
+        dw2, db2 = side_do(lambda: linear_bwd_weight_op(f1, w2, df2))
+        df1 = linear_bwd_data_op(f1, w2, df2, mask_dx_by_x=True)                               # df1 *= [f1>0]
+        dw1, db1 = side_do(lambda: linear_bwd_weight_op(z2f, w1, df1))
+        dz2 = linear_bwd_data_op(z2f, w1, df1, mask_dx_by_x=True)                              # dz2 *= [z2>0]
+        dwf, dbf = side_do(lambda: conv3x3_bwd_weight_op(z.data_ptr(), C * 49, R, C, w_f, dz2, ws))
         dz = torch.empty(R, C, 7, 7, device=dev)
-        dwf, dbf = conv3x3_bwd_op(z.data_ptr(), C * 49, R, C, w_f, pk_f, dz2, dz.data_ptr(), C * 49, ws)
+        conv3x3_bwd_data_op(R, C, pk_f, dz2, dz.data_ptr(), C * 49)
         dx = torch.empty_like(x)
         dlw = torch.empty(R, C, 7, 7, device=dev)
         dlh = torch.empty(R, C, 7, 7, device=dev)
         check(hip.lib().arfe_rff_fuse_bwd(R, C, x.data_ptr(), rs, ptr(lw), ptr(lh), ptr(dz), dx.data_ptr(), rs, ptr(dlw),
                                           ptr(dlh), stream()), "arfe_rff_fuse_bwd")
-        dwwh, dbwh = conv3x3_bwd_op(x.data_ptr() + 4 * C * 49, rs, R, C, w_wh, pk_wh, dlw, dx.data_ptr() + 4 * C * 49, rs, ws)
-        dwhh, dbhh = conv3x3_bwd_op(x.data_ptr() + 8 * C * 49, rs, R, C, w_hh, pk_hh, dlh, dx.data_ptr() + 8 * C * 49, rs, ws)
+        dwwh, dbwh = side_do(lambda: conv3x3_bwd_weight_op(x.data_ptr() + 4 * C * 49, rs, R, C, w_wh, dlw, ws))
+        dwhh, dbhh = side_do(lambda: conv3x3_bwd_weight_op(x.data_ptr() + 8 * C * 49, rs, R, C, w_hh, dlh, ws))
+        side_do(lambda: conv3x3_bwd_data_op(R, C, pk_hh, dlh, dx.data_ptr() + 8 * C * 49, rs))
+        conv3x3_bwd_data_op(R, C, pk_wh, dlw, dx.data_ptr() + 4 * C * 49, rs)
+        join_side(dev)
         return dx, dwwh, dbwh, dwhh, dbhh, dwf, dbf, dw1, db1, dw2, db2, dwc, dbc, dwr, dbr
 
 
