@@ -434,7 +434,7 @@ class RFFHeadFunction(torch.autograd.Function):
         z = torch.empty(R, C, 7, 7, device=x.device)
         check(hip.lib().arfe_rff_fuse_fwd(R, C, base, rs, ptr(lw), ptr(lh), ptr(z), stream()), "arfe_rff_fuse_fwd")
         z2 = conv3x3_fwd_op(z.data_ptr(), C * 49, R, C, pk_f, b_f, True)
-        f1 = linear_fwd_op(z2.view(R, -1), w1, b1, True)
+        f1 = linear_fwd_op(z2.view(R, C * 49), w1, b1, True)
         f2 = linear_fwd_op(f1, w2, b2, True)
         cls = linear_fwd_op(f2, wc, bc, False)
         reg = linear_fwd_op(f2, wr, br, False)
@@ -454,7 +454,7 @@ class RFFHeadFunction(torch.autograd.Function):
         # Every ReLU backward is folded into the epilogue of the kernel that PRODUCES the gradient.
         # Data gradients form the critical chain on the current stream; each parameter gradient is launched on the
         # side stream as soon as its incoming gradient exists.
-        z2f = z2.view(R, -1)
+        z2f = z2.view(R, C * 49)
 
         def side_do(fn):
             return on_side(dev, fn)

@@ -318,3 +318,53 @@ def test_full_size_properties(Fn, O, dev):
     # empty RoI set
     out = Fn.roi_extract(xs, [torch.zeros(0, 5, device=dev)], (4, 8, 16, 32, 64))
     assert out.shape == (0, 256, 7, 7)
+
+
+def test_empty_roi_set_flows_through_extractor_and_head(dev):
+    """R = 0 (an image batch without proposals) must give empty outputs and zero gradients, not a crash."""
+    import arfe_amd
+    C = 8
+    xs = [torch.randn(1, C, h, w, device=dev, requires_grad=True) for h, w in PYRAMIDS['tiny']]
+    roi_head = arfe_amd.build_head(dict(
+        type='StandardRoIHead',
+        bbox_roi_extractor=dict(type='SingleRoIExtractor', roi_layer=dict(type='RoIAlign', out_size=7, sample_num=0),
+                                out_channels=C, featmap_strides=[4, 8, 16, 32, 64]),
+        bbox_head=dict(type='MultiRoIsBBoxHead', in_channels=C, conv_out_channels=C, fc_out_channels=16,
+                       roi_feat_size=7, num_classes=80))).to(dev)
+    roi_head.init_weights()
+    res = roi_head._bbox_forward(xs, torch.zeros(0, 5, device=dev))
+    assert res['cls_score'].shape == (0, 81) and res['bbox_pred'].shape == (0, 320)
+    (res['cls_score'].sum() + res['bbox_pred'].sum()).backward()
+    for p in roi_head.bbox_head.parameters():
+        assert p.grad is not None and p.grad.abs().max().item() == 0.0
+    for x in xs:
+        assert x.grad is None or x.grad.abs().max().item() == 0.0
+
+
+def test_exact_fp32_mode_in_a_fresh_process():
+    """ARFE_GEMM_F32=1 (read once per process) routes every contraction through the exact-fp32 MFMA kernel:
+    the head golden case must then match to summation-order accuracy."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = '''
+import sys, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r + "/tests")
+from conftest import load_golden, relerr
+from arfe_amd import functional as Fn
+dev = torch.device("cuda:0")
+d = load_golden("rff_head_r40.npz")
+x = d["x"].to(dev)
+p = {k[2:]: v.to(dev) for k, v in d.items() if k.startswith("p.")}
+cls, reg = Fn.rff_head(x, p["wh_conv.conv.weight"], p["wh_conv.conv.bias"], p["hh_conv.conv.weight"], p["hh_conv.conv.bias"],
+                       p["final_conv.conv.weight"], p["final_conv.conv.bias"], p["shared_fcs.0.weight"], p["shared_fcs.0.bias"],
+                       p["shared_fcs.1.weight"], p["shared_fcs.1.bias"], p["fc_cls.weight"], p["fc_cls.bias"],
+                       p["fc_reg.weight"], p["fc_reg.bias"])
+e = max(relerr(cls, d["cls"]), relerr(reg, d["reg"]))
+print("ERR", e)
+assert e <= 2e-6, e
+''' % (ROOT, ROOT)
+    env = dict(os.environ, ARFE_GEMM_F32='1')
+    out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
