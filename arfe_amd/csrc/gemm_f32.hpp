@@ -158,42 +158,30 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmDims d, LA la, LB 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // per-thread staging coordinates: 8 elements of A and 8 of B per K-step
+    // staging: operand tile = 128 rows x 2 k-octets = 256 octets -> one octet (8 consecutive k of one row) per thread
+    // and operand, fetched with the branch-free octet loaders (vector loads where k is contiguous)
+    int a_row, a_oct, b_row, b_oct;
+    if (LA::kfast) { a_oct = tid & 1; a_row = tid >> 1; } else { a_row = tid & 127; a_oct = tid >> 7; }
+    if (LB::kfast) { b_oct = tid & 1; b_row = tid >> 1; } else { b_row = tid & 127; b_oct = tid >> 7; }
+    const typename LA::Row arow = la.row(z, m0 + a_row);
+    const typename LB::Row brow = lb.row(z, n0 + b_row);
     float ra[8], rb[8];
     auto fetch = [&](int step) {
-        // k-batch outermost (default) or innermost (kb_inner: the same K-slice of every k-batch back to back,
-        // e.g. the 9 taps of a 3x3 conv re-use one staged channel slice while it is still in L1/L2)
         const int kb = d.kb_inner ? step % d.kb_count : step / ksteps_per_kb;
         const int k0 = (d.kb_inner ? step / d.kb_count : step - kb * ksteps_per_kb) * GEMM_BK;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            int mi, ki;
-            if (LA::kfast) { ki = tid & 15; mi = (tid >> 4) + 16 * i; }
-            else           { mi = tid & 127; ki = (tid >> 7) + 2 * i; }
-            ra[i] = la(z, kb, m0 + mi, k0 + ki);
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            int ni, ki;
-            if (LB::kfast) { ki = tid & 15; ni = (tid >> 4) + 16 * i; }
-            else           { ni = tid & 127; ki = (tid >> 7) + 2 * i; }
-            rb[i] = lb(z, kb, n0 + ni, k0 + ki);
+        if (k0 + GEMM_BK <= d.K) {
+            la.template load8<true>(arow, z, kb, k0 + 8 * a_oct, ra);
+            lb.template load8<true>(brow, z, kb, k0 + 8 * b_oct, rb);
+        } else {
+            la.template load8<false>(arow, z, kb, k0 + 8 * a_oct, ra);
+            lb.template load8<false>(brow, z, kb, k0 + 8 * b_oct, rb);
         }
     };
     auto stash = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            int mi, ki;
-            if (LA::kfast) { ki = tid & 15; mi = (tid >> 4) + 16 * i; }
-            else           { mi = tid & 127; ki = (tid >> 7) + 2 * i; }
-            As[buf][ki][mi] = ra[i];
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            int ni, ki;
-            if (LB::kfast) { ki = tid & 15; ni = (tid >> 4) + 16 * i; }
-            else           { ni = tid & 127; ki = (tid >> 7) + 2 * i; }
-            Bs[buf][ki][ni] = rb[i];
+        for (int j = 0; j < 8; ++j) {
+            As[buf][8 * a_oct + j][a_row] = ra[j];
+            Bs[buf][8 * b_oct + j][b_row] = rb[j];
         }
     };
 
