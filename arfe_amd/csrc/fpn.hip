@@ -351,7 +351,8 @@ __global__ __launch_bounds__(256) void fpn_scatter_bwd_dbsf_kernel(Levels lv, Le
 //   registers (they do not depend on the channel) and each wave handles IB_CG consecutive channels: per channel one 16-B
 //   read of g, 18 scalar weight loads (wave-uniform), 72 FMAs, the pooling term and one 16-B store.
 // =========================================================================================================
-constexpr int IB_CG = 8;
+constexpr int IB_CG = 4;   // channels whose reads are in flight together
+constexpr int IB_NB = 4;   // such batches per wave (amortises the neighbourhood reads of the two maps)
 struct BlockQuadTable {       // pixel quads (B*h*ceil(w/4)) of each level, in whole 64-quad blocks
     int first_blk[NL_ + 1];
     int64_t quads[NL_];
@@ -370,17 +371,21 @@ __global__ __launch_bounds__(256) void fpn_input_bwd_kernel(Levels lv, BlockQuad
     const int lq = threadIdx.x & 63, cw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int lvl = 0;
     while (lvl + 1 < lv.n && (int)blockIdx.x >= bt.first_blk[lvl + 1]) ++lvl;
-    int64_t q = (int64_t)((int)blockIdx.x - bt.first_blk[lvl]) * 64 + lq;
-    const bool active = q < bt.quads[lvl];
-    if (!active) q = 0;                       // idle lanes follow along on quad 0 and never store
+    // quads of a level fit 31 bits (checked on the host): 32-bit divisions only
+    const unsigned q_blk = (unsigned)((int)blockIdx.x - bt.first_blk[lvl]) * 64u;   // always a valid quad
+    unsigned q = q_blk + lq;
+    const bool active = q < (unsigned)bt.quads[lvl];
+    if (!active) q = q_blk;                   // idle lanes follow along on the block's first quad and never store
     const int h = lv.H[lvl], w = lv.W[lvl], wq = bt.wq[lvl];
     const int hr = lv.H[lv.r], wr = lv.W[lv.r];
-    const int x0 = (int)(q % wq) * 4;
-    const int y = (int)((q / wq) % h);
-    const int bi = (int)(q / ((int64_t)wq * h));
+    const unsigned qrow = q / (unsigned)wq;
+    const int x0 = (int)(q - qrow * (unsigned)wq) * 4;
+    const int bi = (int)(qrow / (unsigned)h);
+    const int y = (int)(qrow - (unsigned)bi * (unsigned)h);
     const bool full = x0 + 3 < w;
 
-    // channel-independent neighbourhood of the two maps
+    // channel-independent neighbourhood of the two maps; addresses are clamped into the map and the value is
+    // zeroed by a select, so the 36 loads are unconditional and issue back to back
     float va[3][6], vb[3][6];
     {
         const float* da = dpa.p[lvl] + (int64_t)bi * h * w;
@@ -389,36 +394,152 @@ __global__ __launch_bounds__(256) void fpn_input_bwd_kernel(Levels lv, BlockQuad
         for (int ky = 0; ky < 3; ++ky) {
             const int yy = y - (ky - 1);
             const bool rok = yy >= 0 && yy < h;
+            const int yc = yy < 0 ? 0 : (yy >= h ? h - 1 : yy);
 #pragma unroll
             for (int t = 0; t < 6; ++t) {
                 const int xx = x0 - 1 + t;
                 const bool ok = rok && xx >= 0 && xx < w;
-                va[ky][t] = ok ? da[(int64_t)yy * w + xx] : 0.f;
-                vb[ky][t] = ok ? db[(int64_t)yy * w + xx] : 0.f;
+                const int xc = xx < 0 ? 0 : (xx >= w ? w - 1 : xx);
+                const float ta = da[yc * w + xc], tb = db[yc * w + xc];
+                va[ky][t] = ok ? ta : 0.f;
+                vb[ky][t] = ok ? tb : 0.f;
             }
         }
     }
     const float nlev = (float)lv.n;
     const int64_t plane = (int64_t)h * w, plane_r = (int64_t)hr * wr;
     const int sh = lv.sh[lvl];
-    // conv weights of this block's 4*IB_CG channels -> LDS (the compiler cannot prove the weight tensors are not
-    // aliased by the dx stores, so direct reads would be per-lane vector loads: 18 per channel and thread)
+    // The conv weights are wave-uniform. Read through the constant address space they become scalar loads (the
+    // compiler cannot prove the plain pointers are not aliased by the dx stores and would emit per-lane loads).
     constexpr int CG = MODE == 0 ? IB_CG : 1;   // generic-index levels are tiny: one channel per wave, more workgroups
-    __shared__ float wsm[2][4 * CG][9];
-    {
-        const int cb = blockIdx.y * 4 * CG;
-        for (int i = threadIdx.x; i < 2 * 4 * CG * 9; i += 256) {
-            const int which = i / (4 * CG * 9), rem = i - which * (4 * CG * 9);
-            const int cl = rem / 9;
-            const float* src = which ? w2.p[lvl] : w1.p[lvl];
-            (&wsm[0][0][0])[i] = cb + cl < lv.C ? src[(cb + cl) * 9 + (rem - cl * 9)] : 0.f;
-        }
-    }
+    constexpr int NB = MODE == 0 ? IB_NB : 1;
+    constexpr int CW = CG * NB;                 // channels per wave
+    typedef const float __attribute__((address_space(4)))* const_fp;
+    const const_fp k1g = (const_fp)(uintptr_t)w1.p[lvl], k2g = (const_fp)(uintptr_t)w2.p[lvl];
     // wave cw of block row blockIdx.y owns IB_CG consecutive channels; the loop is fully unrolled so that the
     // global reads of all of them are in flight together
-    const int c_first = (blockIdx.y * 4 + cw) * CG;
-    __syncthreads();
+    const int c_wave = (blockIdx.y * 4 + cw) * CW;
     constexpr bool POW2 = MODE == 0;
+    if constexpr (MODE == 0) {
+        // Shift-only levels carry almost all of the bytes. A wave walks NB batches of CG channels (amortising the
+        // neighbourhood reads above); all global reads of a batch are issued together, ahead of any use: a store
+        // between two channels would fence the next channel's reads (dx may alias the inputs as far as the compiler knows).
+        const int c_last = lv.C - 1;
+        const int e1 = x0 + 1 < w ? 1 : 0, e2 = x0 + 2 < w ? 2 : e1, e3 = x0 + 3 < w ? 3 : e2;
+        const int f0 = y * w + x0;
+        const int64_t oA = (int64_t)(y >> (sh > 0 ? sh : 0)) * wr + (x0 >> (sh > 0 ? sh : 0));
+        const int64_t oB = (int64_t)(y >> (sh > 0 ? sh : 0)) * wr + ((x0 + e2) >> (sh > 0 ? sh : 0));
+        float gq[CG][4], pq[CG][4];   // raw reads of the batch in flight: g and the pooling-term operands
+        int ia[CG], ib[CG];
+        // (the sh branches stay OUTSIDE the channel loops: one basic block holds all reads of a batch)
+        auto issue = [&](int c_first) {
+            int64_t bcs[CG];
+#pragma unroll
+            for (int cj = 0; cj < CG; ++cj) {
+                const int c = c_first + cj < lv.C ? c_first + cj : c_last;
+                bcs[cj] = (int64_t)bi * lv.C + c;
+                const float* gp = gout.p[lvl] + (bcs[cj] * h + y) * (int64_t)w + x0;
+                if (full) {
+                    const float4_u gv = *reinterpret_cast<const float4_u*>(gp);
+                    gq[cj][0] = gv[0]; gq[cj][1] = gv[1]; gq[cj][2] = gv[2]; gq[cj][3] = gv[3];
+                } else {   // clamped addresses; the lanes past the row end are never stored
+                    gq[cj][0] = gp[0]; gq[cj][1] = gp[e1]; gq[cj][2] = gp[e2]; gq[cj][3] = gp[e3];
+                }
+            }
+            if (sh >= 1) {
+                // a finer level below the refine level: windows are the disjoint (1<<sh)^2 blocks, so pixels (0,1)
+                // and (2,3) of the quad share a window
+#pragma unroll
+                for (int cj = 0; cj < CG; ++cj) {
+                    const int32_t* am = argmax + ((int64_t)lvl * lv.B * lv.C + bcs[cj]) * plane_r;
+                    const float* dmp = dm + bcs[cj] * plane_r;
+                    ia[cj] = am[oA]; ib[cj] = am[oB];
+                    pq[cj][0] = dmp[oA]; pq[cj][1] = dmp[oB];
+                }
+            } else if (sh == 0) {
+                // same size as the refine level: the gather is the identity
+#pragma unroll
+                for (int cj = 0; cj < CG; ++cj) {
+                    const float* dp = dm + bcs[cj] * plane_r + (int64_t)y * wr + x0;
+                    if (full) {
+                        const float4_u dv = *reinterpret_cast<const float4_u*>(dp);
+                        pq[cj][0] = dv[0]; pq[cj][1] = dv[1]; pq[cj][2] = dv[2]; pq[cj][3] = dv[3];
+                    } else {
+                        pq[cj][0] = dp[0]; pq[cj][1] = dp[e1]; pq[cj][2] = dp[e2]; pq[cj][3] = dp[e3];
+                    }
+                }
+            } else {
+                // coarser than the refine level (small maps): nearest^T sums the (1<<f)^2 block of dm
+                const int f = -sh, n = 1 << f;
+#pragma unroll
+                for (int cj = 0; cj < CG; ++cj) {
+                    const float* dmp = dm + bcs[cj] * plane_r;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int xx = x0 + e < w ? x0 + e : w - 1;
+                        float sum = 0.f;
+                        for (int py = y << f; py < (y << f) + n; ++py)
+                            for (int px = xx << f; px < (xx << f) + n; ++px) sum += dmp[(int64_t)py * wr + px] / nlev;
+                        pq[cj][e] = sum;
+                    }
+                }
+            }
+        };
+        issue(c_wave);
+#pragma unroll 1
+        for (int nb = 0; nb < NB; ++nb) {
+            const int c_first = c_wave + nb * CG;
+            if (c_first >= lv.C) break;
+            float r[CG][4];
+            if (sh >= 1) {
+#pragma unroll
+                for (int cj = 0; cj < CG; ++cj) {
+                    const float da = pq[cj][0] / nlev, db = pq[cj][1] / nlev;
+                    r[cj][0] = gq[cj][0] + (ia[cj] == f0 ? da : 0.f);
+                    r[cj][1] = gq[cj][1] + (ia[cj] == f0 + 1 ? da : 0.f);
+                    r[cj][2] = gq[cj][2] + (ib[cj] == f0 + 2 ? db : 0.f);
+                    r[cj][3] = gq[cj][3] + (ib[cj] == f0 + 3 ? db : 0.f);
+                }
+            } else {
+                const float dn = sh == 0 ? nlev : 1.f;   // the coarser-level sums are already divided
+#pragma unroll
+                for (int cj = 0; cj < CG; ++cj)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) r[cj][e] = gq[cj][e] + pq[cj][e] / dn;
+            }
+#pragma unroll
+            for (int cj = 0; cj < CG; ++cj) {
+                const int cc = c_first + cj < lv.C ? c_first + cj : c_last;
+                const const_fp k1 = k1g + cc * 9, k2 = k2g + cc * 9;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const float u = k1[ky * 3 + kx], s = k2[ky * 3 + kx];
+                        // dx[y,x] += W[c,ky,kx] * d[y-(ky-1), x-(kx-1)] ; neighbourhood column index = e + 2 - kx
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) r[cj][e] += u * va[ky][e + 2 - kx] + s * vb[ky][e + 2 - kx];
+                    }
+            }
+#pragma unroll
+            for (int cj = 0; cj < CG; ++cj) {
+                if (!active || c_first + cj >= lv.C) continue;
+                float* op = dx.p[lvl] + (((int64_t)bi * lv.C + c_first + cj) * h + y) * (int64_t)w + x0;
+                if (full) {
+                    float4_u o = {r[cj][0], r[cj][1], r[cj][2], r[cj][3]};
+                    *reinterpret_cast<float4_u*>(op) = o;
+                } else {
+                    op[0] = r[cj][0];
+                    if (x0 + 1 < w) op[1] = r[cj][1];
+                    if (x0 + 2 < w) op[2] = r[cj][2];
+                }
+            }
+            // (issuing these reads before the stores above was measured slower, not faster)
+            if (nb + 1 < NB) issue(c_first + CG < lv.C ? c_first + CG : c_first);
+        }
+        return;
+    }
+    const int c_first = c_wave;
 #pragma unroll
     for (int cj = 0; cj < CG; ++cj) {
         const int c = c_first + cj;
@@ -436,8 +557,7 @@ __global__ __launch_bounds__(256) void fpn_input_bwd_kernel(Levels lv, BlockQuad
                 for (int e = 0; e < 4; ++e) r[e] = x0 + e < w ? gp[e] : 0.f;
             }
         }
-        const float* k1 = &wsm[0][cw * CG + cj][0];
-        const float* k2 = &wsm[1][cw * CG + cj][0];
+        const const_fp k1 = k1g + c * 9, k2 = k2g + c * 9;
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -481,7 +601,7 @@ __global__ __launch_bounds__(256) void fpn_input_bwd_kernel(Levels lv, BlockQuad
                     }
                 }
             }
-        } else if (POW2 || sh != SH_GENERAL) {
+        } else if (POW2 || (sh != SH_GENERAL && sh <= 0)) {
             const int f = -sh, n = 1 << f;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -781,14 +901,18 @@ extern "C" int32_t arfe_fpn_input_bwd(const arfe_pyramid_t* pyr, const float* co
         for (int i = 0; i <= NL_; ++i) {
             bt.first_blk[i] = nblk;
             if (i < NL_) {
-                const int mode = i >= lv.n ? -1 : (lv.sh[i] != SH_GENERAL ? 0 : (i >= lv.r ? 1 : 2));
+                const int shi = lv.sh[i];
+                // shift-only kernel: finer-or-equal levels below the refine level, coarser-or-equal ones above it
+                const bool pow2 = shi != SH_GENERAL && (i < lv.r ? shi >= 0 : shi <= 0);
+                const int mode = i >= lv.n ? -1 : (pow2 ? 0 : (i >= lv.r ? 1 : 2));
                 bt.wq[i] = i < lv.n ? cdiv(lv.W[i], 4) : 0;
                 bt.quads[i] = mode == pass ? (int64_t)lv.B * lv.H[i] * bt.wq[i] : 0;
+                ARFE_CHECK_ARG(bt.quads[i] < (int64_t)1 << 31, ARFE_ERR_ARG, "fpn_input_bwd: level %d too large", i);
                 nblk += (int)cdiv64(bt.quads[i], 64);
             }
         }
         if (nblk == 0) continue;
-        const dim3 grid(nblk, cdiv(lv.C, 4 * (pass == 0 ? IB_CG : 1)));
+        const dim3 grid(nblk, cdiv(lv.C, 4 * (pass == 0 ? IB_CG * IB_NB : 1)));
         if (pass == 0)
             hipLaunchKernelGGL((fpn_input_bwd_kernel<0>), grid, dim3(256), 0, as_stream(stream), lv, bt, gp, dap, dbp, w1p,
                                w2p, dm, argmax, dxp);

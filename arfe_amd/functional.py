@@ -75,6 +75,8 @@ def side_stream(device):
 
 def on_side(device, fn):
     """Run fn() on the side stream, ordered after everything already enqueued on the current stream."""
+    if device.type != "cuda":
+        raise hip.ArfeHipError(f"expected tensors on the GPU, got device {device} (there is no CPU path)")
     main = torch.cuda.current_stream()
     side = side_stream(device)
     side.wait_stream(main)
