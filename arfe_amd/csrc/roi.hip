@@ -201,6 +201,7 @@ __device__ __forceinline__ float axis_weight(float start, float bin, int grid, i
 constexpr int RW_EXT = 64;
 // big: 0 table valid, 1 window larger than the table (consumers compute on the fly), 2 no sample inside the map
 struct RoiWeightHdr {
+    int id, lvl, img;               // RoI (set * R + k) of this slot, its level and image
     int y0, x0, big; float inv;
     int hext, wext;                 // rows / columns of the window that carry weight
     int ylo[7], yhi[7];             // row support [ylo, yhi) of bin ph (offsets into the table)
@@ -208,9 +209,12 @@ struct RoiWeightHdr {
 };
 
 __global__ __launch_bounds__(256) void roi_weight_table_kernel(RoiLevels L, RoiSets S, int P, int sample_num,
-                                                               RoiWeightHdr* __restrict__ hdr, float* __restrict__ wtab) {
+                                                               RoiWeightHdr* __restrict__ hdr, float* __restrict__ wtab,
+                                                               const int32_t* __restrict__ order) {
     __shared__ float w_s[2][7][RW_EXT];
-    const int id = blockIdx.x;
+    // slot blockIdx.x of the tables describes RoI order[slot] (forward: spatial processing order) or RoI slot itself
+    const int slot = blockIdx.x;
+    const int id = order ? order[slot] : slot;
     const int s = id / S.R, k = id - s * S.R;
     int lvl = (int)S.levels[s][k];
     lvl = lvl < 0 ? 0 : (lvl >= L.n ? L.n - 1 : lvl);
@@ -220,13 +224,14 @@ __global__ __launch_bounds__(256) void roi_weight_table_kernel(RoiLevels L, RoiS
     const bool oky = axis_range(g.y_start, g.bin_h * (float)P, H, y0, y1);
     const bool okx = axis_range(g.x_start, g.bin_w * (float)P, W, x0, x1);
     const int big = !(oky && okx) ? 2 : ((y1 - y0 >= RW_EXT - 1 || x1 - x0 >= RW_EXT - 1) ? 1 : 0);
-    RoiWeightHdr* h = hdr + id;
+    RoiWeightHdr* h = hdr + slot;
     if (threadIdx.x == 0) {
+        h->id = id; h->lvl = lvl; h->img = (int)S.rois[s][5 * (int64_t)k];
         h->y0 = y0; h->x0 = x0; h->big = big;
         h->inv = 1.0f / (float)(g.grid_h * g.grid_w > 1 ? g.grid_h * g.grid_w : 1);
     }
     if (big) return;
-    float* wt = wtab + (int64_t)id * 2 * 7 * RW_EXT;
+    float* wt = wtab + (int64_t)slot * 2 * 7 * RW_EXT;
     for (int i = threadIdx.x; i < 2 * 7 * RW_EXT; i += 256) {
         const int axis = i / (7 * RW_EXT), rem = i - axis * 7 * RW_EXT;
         const int pb = rem / RW_EXT, off = rem - pb * RW_EXT;
@@ -264,37 +269,79 @@ __global__ __launch_bounds__(256) void roi_weight_table_kernel(RoiLevels L, RoiS
 // issues 4 gathers per sample point), accumulates U[ph] per column while walking down the rows, and finishes
 // with a 49-lane contraction over columns through LDS.  Windows wider/taller than RW_EXT (extreme aspect
 // ratios) take the sampling form inside the same kernel.
-constexpr int RF_CH = 64;
+// Processing order of the forward pass: level, image, then 8-row bands swept left to right, so that the RoIs in flight
+// at any time read one neighbourhood of one feature map (L2 reuse between overlapping RoIs).
+__global__ __launch_bounds__(256) void roi_key_kernel(RoiLevels L, RoiSets S, int n, int P, int sample_num,
+                                                      uint32_t* __restrict__ keys) {
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    if (id >= n) return;
+    const int s = id / S.R, k = id - s * S.R;
+    int lvl = (int)S.levels[s][k];
+    lvl = lvl < 0 ? 0 : (lvl >= L.n ? L.n - 1 : lvl);
+    const float* roi = S.rois[s] + 5 * (int64_t)k;
+    const RoiGeom g = roi_geom(roi, L.scale[lvl], P, sample_num);
+    int y0 = 0, y1 = -1, x0 = 0, x1 = -1;
+    axis_range(g.y_start, g.bin_h * (float)P, L.H[lvl], y0, y1);
+    axis_range(g.x_start, g.bin_w * (float)P, L.W[lvl], x0, x1);
+    const int img = (int)roi[0];
+    keys[id] = ((uint32_t)lvl << 29) | (((uint32_t)img & 0x1ffu) << 20) | ((((uint32_t)y0 >> 3) & 0x3ffu) << 10) |
+               (((uint32_t)x0 >> 2) & 0x3ffu);
+}
+
+// order[rank] = id, rank = number of RoIs with a smaller (key, id): a counting rank is enough for a few thousand RoIs
+__global__ __launch_bounds__(256) void roi_rank_kernel(int n, const uint32_t* __restrict__ keys, int32_t* __restrict__ order) {
+    __shared__ uint32_t ks[1024];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t mine = i < n ? keys[i] : 0u;
+    int rank = 0;
+    for (int base = 0; base < n; base += 1024) {
+        const int cnt = n - base < 1024 ? n - base : 1024;
+        __syncthreads();
+        for (int j = threadIdx.x; j < cnt; j += 256) ks[j] = keys[base + j];
+        __syncthreads();
+        for (int j = 0; j < cnt; ++j) {
+            const uint32_t o = ks[j];
+            rank += (o < mine || (o == mine && base + j < i)) ? 1 : 0;
+        }
+    }
+    if (i < n) order[rank] = i;
+}
+
+constexpr int RF_CH = 32;   // channels per block: C/32 = 8 slices of a 256-channel map, one per XCD (see the block map)
 __global__ __launch_bounds__(256) void roialign_fwd_sep_kernel(RoiLevels L, RoiSets S, int P, int sample_num,
                                                                const RoiWeightHdr* __restrict__ hdr,
-                                                               const float* __restrict__ wtab, float* __restrict__ out,
-                                                               int64_t out_roi_stride) {
+                                                               const float* __restrict__ wtab, int nslices,
+                                                               float* __restrict__ out, int64_t out_roi_stride) {
     __shared__ float wy_s[7][RW_EXT], wx_s[7][RW_EXT];
     __shared__ float U_s[4][7][RW_EXT];
     __shared__ RoiWeightHdr h_s;
-    const int id = blockIdx.x;
+    // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2): the channel slice is the fast index, so
+    // with 8 slices an XCD only ever sees its own 32 channels of the pyramid, and the RoIs come in spatial order.
+    // Slot r of the header / weight tables was written for the r-th RoI of that order, so everything this workgroup
+    // needs hangs off blockIdx alone (one global round trip before the window reads, not a chain of four).
+    const int slot = blockIdx.x / nslices;
+    const RoiWeightHdr* hp = hdr + slot;
+    const int id = hp->id;
     const int s = id / S.R, k = id - s * S.R;
-    const int c0 = blockIdx.y * RF_CH;
+    const int c0 = (blockIdx.x % nslices) * RF_CH;
     const int ncc = L.C - c0 < RF_CH ? L.C - c0 : RF_CH;
-    int lvl = (int)S.levels[s][k];
-    lvl = lvl < 0 ? 0 : (lvl >= L.n ? L.n - 1 : lvl);
+    const int lvl = hp->lvl;
     int H = L.H[0], W = L.W[0];
     const float* feat = L.feat[0];
 #pragma unroll
     for (int i = 1; i < ARFE_MAX_LEVELS; ++i)
         if (i == lvl) { H = L.H[i]; W = L.W[i]; feat = L.feat[i]; }
-    const float* roi = S.rois[s] + 5 * (int64_t)k;
-    const int bimg = (int)roi[0];
+    const int bimg = hp->img;
     float* obase = out + (int64_t)k * out_roi_stride + ((int64_t)s * L.C + c0) * 49;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int big = hdr[id].big;
+    const int big = hp->big;
 
     if (big == 2) {     // every sample falls outside the feature map (or negative size): zeros
         for (int o = tid; o < ncc * 49; o += 256) obase[o] = 0.f;
         return;
     }
     if (big) {          // sampling form (reference order), one thread per output element
-        const RoiGeom g = roi_geom(roi, L.scale[lvl], P, sample_num);
+        const RoiGeom g = roi_geom(S.rois[s] + 5 * (int64_t)k, L.scale[lvl], P, sample_num);
         for (int o = tid; o < ncc * 49; o += 256) {
             const int c = o / 49, q = o - c * 49, ph = q / 7, pw = q - ph * 7;
             const float* f = feat + ((int64_t)bimg * L.C + c0 + c) * H * W;
@@ -317,19 +364,20 @@ __global__ __launch_bounds__(256) void roialign_fwd_sep_kernel(RoiLevels L, RoiS
         return;
     }
     // ---- header + weight tables -> LDS ----
-    if (tid < (int)(sizeof(RoiWeightHdr) / sizeof(int))) ((int*)&h_s)[tid] = ((const int*)(hdr + id))[tid];
-    const float* wt = wtab + (int64_t)id * 2 * 7 * RW_EXT;
-    const float inv = hdr[id].inv;
+    if (tid < (int)(sizeof(RoiWeightHdr) / sizeof(int))) ((int*)&h_s)[tid] = ((const int*)hp)[tid];
+    const float* wt = wtab + (int64_t)slot * 2 * 7 * RW_EXT;
+    const float inv = hp->inv;
     for (int i = tid; i < 7 * RW_EXT; i += 256) {
         (&wy_s[0][0])[i] = wt[i] * inv;
         (&wx_s[0][0])[i] = wt[7 * RW_EXT + i];
     }
     __syncthreads();
     const int wext = h_s.wext;
-    // windows up to 32 columns wide (the common case) put two channels on one wave
-    const int pack = wext <= 32 ? 2 : 1;
-    const int half = pack == 2 ? lane >> 5 : 0;
-    const int col = pack == 2 ? lane & 31 : lane;
+    // A lane is one window column; narrow windows put 4 (<= 16 columns) or 2 (<= 32) channels on one wave, so that a
+    // row read (one dword per lane: it costs the address unit as much as a 16-byte one) carries several channels.
+    const int psh = wext <= 16 ? 2 : (wext <= 32 ? 1 : 0), pack = 1 << psh, pw_cols = 64 >> psh;
+    const int half = lane >> (6 - psh);
+    const int col = lane & (pw_cols - 1);
     const bool col_ok = col < wext;
     const int q = lane < 49 ? lane : 48, qph = q / 7, qpw = q - qph * 7;
     const int xlo = h_s.xlo[qpw], xhi = h_s.xhi[qpw];
@@ -350,13 +398,14 @@ __global__ __launch_bounds__(256) void roialign_fwd_sep_kernel(RoiLevels L, RoiS
         for (int hh = 0; hh < pack; ++hh) {
             if (lane < 49 && cb + hh < ncc) {
                 float acc = 0.f;
-                for (int x = xlo; x < xhi; ++x) acc += U_s[wave][qph][hh * 32 + x] * wx_s[qpw][x];
+                for (int x = xlo; x < xhi; ++x) acc += U_s[wave][qph][hh * pw_cols + x] * wx_s[qpw][x];
                 obase[(cb + hh) * 49 + lane] = acc;
             }
         }
         __builtin_amdgcn_wave_barrier();
     }
 }
+
 
 // One workgroup = (16x16 feature tile, RB_CC channels).  RoIs of the tile's list are taken RB_NB at a time so
 // that the dependent global reads of a batch (list -> roi -> G) overlap, and the column contraction
@@ -584,7 +633,7 @@ extern "C" int32_t arfe_map_roi_levels(int32_t R, const float* rois, int32_t num
 
 extern "C" int64_t arfe_roialign_fwd_workspace_bytes(int32_t nsets, int32_t R) {
     if (nsets < 1 || nsets > RB_MAXSETS || R < 0) return -1;
-    return (int64_t)nsets * R * ((int64_t)sizeof(RoiWeightHdr) + (int64_t)2 * 7 * RW_EXT * sizeof(float)) + 64;
+    return (int64_t)nsets * R * ((int64_t)sizeof(RoiWeightHdr) + (int64_t)2 * 7 * RW_EXT * sizeof(float) + 8) + 64;
 }
 
 extern "C" int32_t arfe_roialign_fwd(const arfe_pyramid_t* pyr, const float* const* feats, const int32_t* strides,
@@ -610,10 +659,19 @@ extern "C" int32_t arfe_roialign_fwd(const arfe_pyramid_t* pyr, const float* con
     RoiWeightHdr* hdr = (RoiWeightHdr*)workspace;
     float* wtab = (float*)(hdr + nroi);
     hipStream_t st = as_stream(stream);
-    hipLaunchKernelGGL(roi_weight_table_kernel, dim3(nroi), dim3(256), 0, st, L, S, pooled, sample_num, hdr, wtab);
+    uint32_t* keys = (uint32_t*)(wtab + (int64_t)nroi * 2 * 7 * RW_EXT);
+    int32_t* order = (int32_t*)(keys + nroi);
+    const int nslices = cdiv(L.C, RF_CH);
+    ARFE_CHECK_ARG((int64_t)nroi * nslices < (int64_t)1 << 31, ARFE_ERR_ARG, "roialign_fwd: too many RoIs");
+    hipLaunchKernelGGL(roi_key_kernel, dim3(cdiv(nroi, 256)), dim3(256), 0, st, L, S, nroi, pooled, sample_num, keys);
     ARFE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(roialign_fwd_sep_kernel, dim3(nroi, cdiv(L.C, RF_CH)), dim3(256), 0, st, L, S, pooled, sample_num,
-                       (const RoiWeightHdr*)hdr, (const float*)wtab, out, out_roi_stride);
+    hipLaunchKernelGGL(roi_rank_kernel, dim3(cdiv(nroi, 256)), dim3(256), 0, st, nroi, (const uint32_t*)keys, order);
+    ARFE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(roi_weight_table_kernel, dim3(nroi), dim3(256), 0, st, L, S, pooled, sample_num, hdr, wtab,
+                       (const int32_t*)order);
+    ARFE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(roialign_fwd_sep_kernel, dim3(nroi * nslices), dim3(256), 0, st, L, S, pooled, sample_num,
+                       (const RoiWeightHdr*)hdr, (const float*)wtab, nslices, out, out_roi_stride);
     ARFE_CHECK_LAUNCH();
     return ARFE_OK;
 }
@@ -701,7 +759,7 @@ extern "C" int32_t arfe_roialign_bwd(const arfe_pyramid_t* pyr, float* const* df
             return ARFE_ERR_LAUNCH;
         }
     if (nroi > 0) {
-        hipLaunchKernelGGL(roi_weight_table_kernel, dim3(nroi), dim3(256), 0, st, L, S, pooled, sample_num, hdr, wtab);
+        hipLaunchKernelGGL(roi_weight_table_kernel, dim3(nroi), dim3(256), 0, st, L, S, pooled, sample_num, hdr, wtab, (const int32_t*)nullptr);
         ARFE_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(roialign_bwd_tiles_kernel, dim3(ntiles, cdiv(L.C, RB_CC), RB_SEGS), dim3(256), 0, st, L, S, T, pooled,

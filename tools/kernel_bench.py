@@ -41,7 +41,7 @@ def linear(R, i, o):
     print(f"linear fwd R={R} in={i} out={o}: {ms*1e3:8.1f} us  {fl/ms/1e9:7.1f} TFLOP/s")
 
 
-if __name__ == '__main__':
+if __name__ == "__main__":
     for R in (700, 940, 980, 1024, 1100, 1960, 2048):
         conv(R)
     linear(4096, 4096, 4096)
