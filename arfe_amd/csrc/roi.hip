@@ -307,12 +307,14 @@ __global__ __launch_bounds__(256) void roi_rank_kernel(int n, const uint32_t* __
     if (i < n) order[rank] = i;
 }
 
+constexpr int RF_ROWS = 8;  // window rows in flight per lane
 constexpr int RF_CH = 32;   // channels per block: C/32 = 8 slices of a 256-channel map, one per XCD (see the block map)
 __global__ __launch_bounds__(256) void roialign_fwd_sep_kernel(RoiLevels L, RoiSets S, int P, int sample_num,
                                                                const RoiWeightHdr* __restrict__ hdr,
                                                                const float* __restrict__ wtab, int nslices,
                                                                float* __restrict__ out, int64_t out_roi_stride) {
-    __shared__ float wy_s[7][RW_EXT], wx_s[7][RW_EXT];
+    __shared__ __attribute__((aligned(16))) float wyT_s[RW_EXT][8];   // [window row][bin], pre-scaled by 1/samples
+    __shared__ float wx_s[7][RW_EXT];
     __shared__ float U_s[4][7][RW_EXT];
     __shared__ RoiWeightHdr h_s;
     // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2): the channel slice is the fast index, so
@@ -368,38 +370,50 @@ __global__ __launch_bounds__(256) void roialign_fwd_sep_kernel(RoiLevels L, RoiS
     const float* wt = wtab + (int64_t)slot * 2 * 7 * RW_EXT;
     const float inv = hp->inv;
     for (int i = tid; i < 7 * RW_EXT; i += 256) {
-        (&wy_s[0][0])[i] = wt[i] * inv;
+        const int pb = i / RW_EXT, off = i - pb * RW_EXT;
+        wyT_s[off][pb] = wt[i] * inv;
         (&wx_s[0][0])[i] = wt[7 * RW_EXT + i];
     }
+    if (tid < RW_EXT) wyT_s[tid][7] = 0.f;
     __syncthreads();
-    const int wext = h_s.wext;
+    const int wext = h_s.wext, hext = h_s.hext;
     // A lane is one window column; narrow windows put 4 (<= 16 columns) or 2 (<= 32) channels on one wave, so that a
     // row read (one dword per lane: it costs the address unit as much as a 16-byte one) carries several channels.
+    // Every window row is read ONCE, eight rows in flight, and folded into all seven bins with the row's weight
+    // vector (zero outside a bin's support) - no per-bin loops whose reads would queue behind each other.
     const int psh = wext <= 16 ? 2 : (wext <= 32 ? 1 : 0), pack = 1 << psh, pw_cols = 64 >> psh;
     const int half = lane >> (6 - psh);
     const int col = lane & (pw_cols - 1);
-    const bool col_ok = col < wext;
+    const int colc = col < wext ? col : wext - 1;          // lanes past the window re-read its last column (unused)
     const int q = lane < 49 ? lane : 48, qph = q / 7, qpw = q - qph * 7;
     const int xlo = h_s.xlo[qpw], xhi = h_s.xhi[qpw];
     for (int cb = wave * pack; cb < ncc; cb += 4 * pack) {
         const int c = cb + half;
-        const bool c_ok = c < ncc && col_ok;
-        const float* f = feat + (((int64_t)bimg * L.C + c0 + (c < ncc ? c : cb)) * H + h_s.y0) * W + h_s.x0 + col;
+        const float* f = feat + (((int64_t)bimg * L.C + c0 + (c < ncc ? c : cb)) * H + h_s.y0) * W + h_s.x0 + colc;
+        float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int y = 0; y < hext; y += RF_ROWS) {
+            float v[RF_ROWS];
 #pragma unroll
-        for (int ph = 0; ph < 7; ++ph) {
-            float acc = 0.f;
-            const int ylo = h_s.ylo[ph], yhi = h_s.yhi[ph];
-#pragma unroll 4
-            for (int y = ylo; y < yhi; ++y) acc += wy_s[ph][y] * (c_ok ? f[(int64_t)y * W] : 0.f);
-            U_s[wave][ph][lane] = acc;
+            for (int j = 0; j < RF_ROWS; ++j) v[j] = f[(int64_t)(y + j < hext ? y + j : hext - 1) * W];
+#pragma unroll
+            for (int j = 0; j < RF_ROWS; ++j) {
+                if (y + j < hext) {
+                    const float4_u wa = *reinterpret_cast<const float4_u*>(&wyT_s[y + j][0]);
+                    const float4_u wb = *reinterpret_cast<const float4_u*>(&wyT_s[y + j][4]);
+                    acc[0] += wa[0] * v[j]; acc[1] += wa[1] * v[j]; acc[2] += wa[2] * v[j]; acc[3] += wa[3] * v[j];
+                    acc[4] += wb[0] * v[j]; acc[5] += wb[1] * v[j]; acc[6] += wb[2] * v[j];
+                }
+            }
         }
+#pragma unroll
+        for (int ph = 0; ph < 7; ++ph) U_s[wave][ph][lane] = acc[ph];
         __builtin_amdgcn_s_waitcnt(0xc07f);     // lgkmcnt(0): this wave's U_s writes have landed
         __builtin_amdgcn_wave_barrier();
         for (int hh = 0; hh < pack; ++hh) {
             if (lane < 49 && cb + hh < ncc) {
-                float acc = 0.f;
-                for (int x = xlo; x < xhi; ++x) acc += U_s[wave][qph][hh * pw_cols + x] * wx_s[qpw][x];
-                obase[(cb + hh) * 49 + lane] = acc;
+                float acc2 = 0.f;
+                for (int x = xlo; x < xhi; ++x) acc2 += U_s[wave][qph][hh * pw_cols + x] * wx_s[qpw][x];
+                obase[(cb + hh) * 49 + lane] = acc2;
             }
         }
         __builtin_amdgcn_wave_barrier();
