@@ -433,13 +433,16 @@ __global__ __launch_bounds__(256) void roialign_bwd_tiles_kernel(RoiLevels L, Ro
                                                                  const float* __restrict__ gout, int64_t g_roi_stride,
                                                                  const int* __restrict__ offsets, const int* __restrict__ list,
                                                                  const RoiWeightHdr* __restrict__ hdr,
-                                                                 const float* __restrict__ wtab) {
+                                                                 const float* __restrict__ wtab, int ntiles, int nchunks) {
     __shared__ __attribute__((aligned(16))) float G_s[RB_NB][RB_CC][7][8];       // [roi][c][ph][pw (+1 pad)]
     __shared__ __attribute__((aligned(16))) float T_s[RB_NB][7][RB_CC / 4][RT][4];  // [roi][ph][c/4][x][c%4]
     __shared__ __attribute__((aligned(16))) float wy_s[RB_NB][RT][8], wx_s[RB_NB][RT][8];
     // coarse levels hold few tiles with long RoI lists: dispatch them first (reverse tile order) and cut a long
     // list into RB_SEGS slices handled by different workgroups (those add atomically into the zeroed output)
-    int tile = (int)gridDim.x - 1 - (int)blockIdx.x, lvl = 0;
+    // The channel chunk is the fast index of blockIdx.x: workgroups go round-robin to the 8 XCDs, so (16 chunks) an XCD
+    // always works on the same two chunks, and the neighbouring tiles that re-read a RoI's gradient block for that
+    // chunk follow each other on the same L2 (tile-fast order sent them to eight different L2s: 15 % hit rate).
+    int tile = ntiles - 1 - (int)(blockIdx.x / (unsigned)nchunks), lvl = 0;
     const int lbeg = offsets[tile], lend = offsets[tile + 1];
     const int nseg = (lend - lbeg) > RB_SEG_MIN ? RB_SEGS : 1;
     const int seg = blockIdx.z;
@@ -451,7 +454,7 @@ __global__ __launch_bounds__(256) void roialign_bwd_tiles_kernel(RoiLevels L, Ro
     const int b = local / (T.tiles_x[lvl] * T.tiles_y[lvl]);
     const int H = L.H[lvl], W = L.W[lvl];
     const float scale = L.scale[lvl];
-    const int c0 = blockIdx.y * RB_CC;
+    const int c0 = (int)(blockIdx.x % (unsigned)nchunks) * RB_CC;
     const int ncc = L.C - c0 < RB_CC ? L.C - c0 : RB_CC;
     const int tid = threadIdx.x, py = tid >> 4, px = tid & 15;
     const int y = ty * RT + py, x = tx * RT + px;
@@ -776,9 +779,11 @@ extern "C" int32_t arfe_roialign_bwd(const arfe_pyramid_t* pyr, float* const* df
         hipLaunchKernelGGL(roi_weight_table_kernel, dim3(nroi), dim3(256), 0, st, L, S, pooled, sample_num, hdr, wtab, (const int32_t*)nullptr);
         ARFE_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(roialign_bwd_tiles_kernel, dim3(ntiles, cdiv(L.C, RB_CC), RB_SEGS), dim3(256), 0, st, L, S, T, pooled,
+    const int nchunks = cdiv(L.C, RB_CC);
+    ARFE_CHECK_ARG((int64_t)ntiles * nchunks < (int64_t)1 << 31, ARFE_ERR_ARG, "roialign_bwd: pyramid too large");
+    hipLaunchKernelGGL(roialign_bwd_tiles_kernel, dim3(ntiles * nchunks, 1, RB_SEGS), dim3(256), 0, st, L, S, T, pooled,
                        sample_num, gout, gout_roi_stride, (const int*)offsets, (const int*)list,
-                       (const RoiWeightHdr*)hdr, (const float*)wtab);
+                       (const RoiWeightHdr*)hdr, (const float*)wtab, ntiles, nchunks);
     ARFE_CHECK_LAUNCH();
     return ARFE_OK;
 }
