@@ -172,6 +172,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmDims d, LA la, 
 // runs at only ~79 B/clk) and each fragment read feeds 1.5x the MFMAs.  The two LDS buffers (2 x 80 KB = the
 // whole 160 KB of a CU) give one barrier per K-step: iteration s splits+stores step s+1 into the other buffer and
 // issues the global loads of step s+2 around the 48 MFMAs of step s.
+// Measured decomposition on the conv shape (M=256, N=50176, K=9x256; tools/mfma_calib.py): MFMA + fragment reads alone
+// 173 us, staging alone (loads + split + LDS stores) 174 us, both 250 us; hipBLASLt needs 209 us for a plain bf16 GEMM
+// with the same MFMA work.  The kernel sits at the 256-register limit of 2 waves/SIMD (128 accumulators + 48 fragment
+// + 32 staging registers), which is what keeps the two halves from overlapping further.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int XL_BM = 256, XL_BN = 256;
 constexpr int XL_LDS_BYTES = 2 * 2 * (XL_BM + XL_BN) * XB_LD * 2;      // 163840
@@ -245,6 +249,32 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_large_kernel(GemmDims d, L
             for (int i = 0; i < 2; ++i) lb.template load8<false>(brow[i], z, kb, k0 + 8 * b_oct[i], rb[i]);
         }
     };
+    // steady-state form for K a multiple of the K-step: no branch at all, so that the whole iteration is ONE
+    // scheduling region and the loads can be placed between the MFMAs
+    // The (k-batch, inner step) pair of the step being fetched is carried and advanced with selects: the division
+    // form above would put scalar branches into the loop body.
+    int f_kb = 0, f_ks = 0;
+    auto fetch_seek = [&](int step) {
+        f_kb = d.kb_inner ? step % d.kb_count : step / ksteps_per_kb;
+        f_ks = d.kb_inner ? step / d.kb_count : step - f_kb * ksteps_per_kb;
+    };
+    auto fetch_full = [&]() {
+        const int kb = f_kb, k0 = f_ks * XB_BK;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) la.template load8<true>(arow[i], z, kb, k0 + 8 * a_oct[i], ra[i]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) lb.template load8<true>(brow[i], z, kb, k0 + 8 * b_oct[i], rb[i]);
+        // advance to the next step
+        const int inner = d.kb_inner;
+        int kb2 = f_kb + inner, ks2 = f_ks + 1 - inner;
+        const bool wrap_kb = kb2 == d.kb_count;               // only reachable with kb_inner
+        ks2 += (inner & (wrap_kb ? 1 : 0));
+        kb2 = wrap_kb ? 0 : kb2;
+        const bool wrap_ks = (inner == 0) & (ks2 == ksteps_per_kb);
+        kb2 += wrap_ks ? 1 : 0;
+        ks2 = wrap_ks ? 0 : ks2;
+        f_kb = kb2; f_ks = ks2;
+    };
     auto stash_a = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -298,25 +328,30 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_large_kernel(GemmDims d, L
         int s = s_begin;
         // steady state (branch-free body = one scheduling region): the split+store of step s+1 and the global loads of
         // step s+2 are interleaved with the 48 MFMAs of step s by the scheduler directives below
-        for (; s + 2 < s_end; ++s) {
-            stash_a(buf ^ 1);
-            mma(buf, 0);
-            stash_b(buf ^ 1);
-            fetch(s + 2);
-            mma(buf, 16);
-#if !defined(ARFE_NO_SCHED_GROUPS)
-            // per MFMA: a few VALU (operand split), then LDS / global traffic spread over the MFMA stream
-#pragma unroll
-            for (int g = 0; g < 48; ++g) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
-                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // 4 VALU
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
-                if (g % 3 == 0) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
-                if (g % 2 == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+        if (d.K % XB_BK == 0) {
+            // branch-free body = ONE scheduling region: the compiler places the split + LDS stores of step s+1 and the
+            // global loads of step s+2 between the 48 MFMAs of step s (hand-written sched_group_barrier patterns were
+            // measured slower than its own choice here)
+            fetch_seek(s + 2);
+            for (; s + 2 < s_end; ++s) {
+                stash_a(buf ^ 1);
+                mma(buf, 0);
+                stash_b(buf ^ 1);
+                fetch_full();
+                mma(buf, 16);
+                __syncthreads();
+                buf ^= 1;
             }
-#endif
-            __syncthreads();
-            buf ^= 1;
+        } else {
+            for (; s + 2 < s_end; ++s) {       // K tail somewhere: the bound-checked loaders (branches in the body)
+                stash_a(buf ^ 1);
+                mma(buf, 0);
+                stash_b(buf ^ 1);
+                fetch(s + 2);
+                mma(buf, 16);
+                __syncthreads();
+                buf ^= 1;
+            }
         }
         for (; s < s_end; ++s) {       // last two steps: nothing left to fetch / stash
             const bool more = s + 1 < s_end;
@@ -379,7 +414,18 @@ static inline int32_t launch_gemm_auto(int M, int N, int K, int kb_count, int ba
     if (splitk < 1) splitk = 1;
     if (splitk > d.ksteps_total && d.ksteps_total > 0) splitk = d.ksteps_total;
     int splitk_large = splitk;
-    if (plan_large_tile(M, N, batch, d.ksteps_total, &splitk_large)) {
+    bool use_large = plan_large_tile(M, N, batch, d.ksteps_total, &splitk_large);
+    {   // tuning aid (tools/gemm_sweep.py): ARFE_GEMM_PLAN=L<k> / S<k> forces the tile and, for callers that already
+        // take the atomic split-K path, the slice count
+        static const char* plan = getenv("ARFE_GEMM_PLAN");
+        if (plan && (plan[0] == 'L' || plan[0] == 'S')) {
+            use_large = plan[0] == 'L';
+            const int k = atoi(plan + 1);
+            if (k >= 1 && splitk > 1) { splitk = k < d.ksteps_total ? k : d.ksteps_total; splitk_large = splitk; }
+            else if (use_large) splitk_large = splitk;
+        }
+    }
+    if (use_large) {
         splitk = splitk_large;
         d.splitk = splitk;
         d.tiles_m = cdiv(M, XL_BM); d.tiles_n = cdiv(N, XL_BN);
