@@ -21,13 +21,25 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int XB_BK = 32;
 constexpr int XB_LD = 40;   // bf16 elements per LDS row (32 + 8 pad)
 
+// Pairs are converted with one v_cvt_pk_bf16_f32 each and kept as packed 32-bit words all the way to the 16-byte LDS
+// store (element-wise __bf16 code compiled to 2.5x the conversions plus ~35 register moves per octet, all of them on
+// the issue port the MFMAs share): 4 cvt + 8 unpack + 4 v_pk_add_f32 + 4 cvt = 20 vector instructions per octet.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+    u32x4 h, l;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const __bf16 h = (__bf16)v[j];
-        hi[j] = h;
-        lo[j] = (__bf16)(v[j] - (float)h);
+    for (int j = 0; j < 4; ++j) {
+        const f32x2 x = {v[2 * j], v[2 * j + 1]};
+        const unsigned hw = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2));
+        const f32x2 hf = {__uint_as_float(hw << 16), __uint_as_float(hw & 0xffff0000u)};
+        const f32x2 r = x - hf;
+        h[j] = hw;
+        l[j] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
     }
+    hi = __builtin_bit_cast(bf16x8, h);
+    lo = __builtin_bit_cast(bf16x8, l);
 }
 
 template <class LA, class LB, class EPI>
@@ -330,8 +342,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_large_kernel(GemmDims d, L
         // step s+2 are interleaved with the 48 MFMAs of step s by the scheduler directives below
         if (d.K % XB_BK == 0) {
             // branch-free body = ONE scheduling region: the compiler places the split + LDS stores of step s+1 and the
-            // global loads of step s+2 between the 48 MFMAs of step s (hand-written sched_group_barrier patterns were
-            // measured slower than its own choice here)
+            // global loads of step s+2 between the 48 MFMAs of step s (hand-written sched_group_barrier patterns, and a
+            // ping-pong order in which SIMD partner waves alternate MFMA and staging halves, were both measured slower)
             fetch_seek(s + 2);
             for (; s + 2 < s_end; ++s) {
                 stash_a(buf ^ 1);

@@ -66,9 +66,9 @@ struct LoadRowMajorK {   // element(i, k) = p[z*sz + kb*skb + i*ld + k]     (k c
     __device__ __forceinline__ void load8(const Row& r, int, int kb, int k0, float (&v)[8]) const {
         const float* q = r.q + kb * skb;
         if (FULLK) {
+            // rows past the matrix were clamped by row(): they yield copies of the last row, whose products only reach
+            // output rows/columns the epilogue never stores - no zeroing (8 selects per octet on the MFMA issue port)
             ld8_contig(q + k0, v);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = r.ok ? v[j] : 0.f;
         } else {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -94,7 +94,7 @@ struct LoadRowMajorI {   // element(i, k) = p[z*sz + kb*skb + k*ld + i]     (i c
         for (int j = 0; j < 8; ++j) {
             const int k = k0 + j;
             const float t = q[(int64_t)(FULLK || k < K ? k : K - 1) * ld];
-            v[j] = (r.ok && (FULLK || k < K)) ? t : 0.f;
+            v[j] = FULLK ? t : ((r.ok && k < K) ? t : 0.f);     // FULLK: clamped rows need no zeroing (see LoadRowMajorK)
         }
     }
 };

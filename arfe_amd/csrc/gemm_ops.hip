@@ -8,6 +8,8 @@ namespace arfe {
 // loaders with an optional ReLU mask (value is zeroed where mask <= 0; mask shares the value's indexing)
 // ---------------------------------------------------------------------------------------------------------
 // ---- 3x3 conv on [R,C,7,7] RoI tiles as 9 shifted GEMMs (k-batch = tap) ------------------------------------
+__device__ const float CONV_ZEROS[8 * 49] = {};   // what a padding tap of the 3x3 convs reads
+
 struct ConvGatherB {   // B(n=(r,p), k=ci) for tap kb: x[r*roi_stride + ci*49 + shift(p, tap)], 0 outside the 7x7 tile
     const float* x; int64_t roi_stride; int N, Cin;
     static constexpr bool kfast = false;
@@ -32,14 +34,21 @@ struct ConvGatherB {   // B(n=(r,p), k=ci) for tap kb: x[r*roi_stride + ci*49 + 
     template <bool FULLK>
     __device__ __forceinline__ void load8(const Row& r, int, int kb, int k0, float (&v)[8]) const {
         const int yy = r.py + kb / 3 - 1, xx = r.px + kb % 3 - 1;
-        const bool inside = r.ok && (unsigned)yy < 7u && (unsigned)xx < 7u;
-        // padding taps read a valid (clamped) address and are zeroed: no branch, all 8 loads issue together
-        const float* q = r.xb + (inside ? yy * 7 + xx : 0);
+        const bool inside = (unsigned)yy < 7u && (unsigned)xx < 7u;
+        if (FULLK) {
+            // padding taps read a block of zeros instead (pointer select: 3 selects per octet, not 8); rows past N are
+            // clamped copies that only reach columns the epilogue never stores
+            const float* q = inside ? r.xb + (k0 * 49 + yy * 7 + xx) : CONV_ZEROS;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = k0 + j;
-            const float t = q[(FULLK || k < Cin ? k : Cin - 1) * 49];
-            v[j] = (inside && (FULLK || k < Cin)) ? t : 0.f;
+            for (int j = 0; j < 8; ++j) v[j] = q[j * 49];
+        } else {
+            const float* q = r.xb + (inside ? yy * 7 + xx : 0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = k0 + j;
+                const float t = q[(k < Cin ? k : Cin - 1) * 49];
+                v[j] = (r.ok && inside && k < Cin) ? t : 0.f;
+            }
         }
     }
 };
