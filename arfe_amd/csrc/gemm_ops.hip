@@ -8,10 +8,9 @@ namespace arfe {
 // loaders with an optional ReLU mask (value is zeroed where mask <= 0; mask shares the value's indexing)
 // ---------------------------------------------------------------------------------------------------------
 // ---- 3x3 conv on [R,C,7,7] RoI tiles as 9 shifted GEMMs (k-batch = tap) ------------------------------------
-__device__ const float CONV_ZEROS[8 * 49] = {};   // what a padding tap of the 3x3 convs reads
-
 struct ConvGatherB {   // B(n=(r,p), k=ci) for tap kb: x[r*roi_stride + ci*49 + shift(p, tap)], 0 outside the 7x7 tile
     const float* x; int64_t roi_stride; int N, Cin;
+    const float* zeros;     // 8*49 zero floats in global memory: what a padding tap reads
     static constexpr bool kfast = false;
     __device__ __forceinline__ float operator()(int, int kb, int n, int k) const {
         if (n >= N || k >= Cin) return 0.f;
@@ -38,7 +37,15 @@ struct ConvGatherB {   // B(n=(r,p), k=ci) for tap kb: x[r*roi_stride + ci*49 + 
         if (FULLK) {
             // padding taps read a block of zeros instead (pointer select: 3 selects per octet, not 8); rows past N are
             // clamped copies that only reach columns the epilogue never stores
-            const float* q = inside ? r.xb + (k0 * 49 + yy * 7 + xx) : CONV_ZEROS;
+            // (the choice is spelled as two v_cndmask: a C ternary is turned back into a predicated block around the
+            // address arithmetic, which cuts the K-step into several scheduling regions)
+            const uint64_t qin = (uint64_t)(uintptr_t)(r.xb + (k0 * 49 + yy * 7 + xx)), qz = (uint64_t)(uintptr_t)zeros;
+            const uint64_t lanes = __builtin_amdgcn_ballot_w64(inside);
+            unsigned q_lo, q_hi;
+            asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(q_lo) : "v"((unsigned)qz), "v"((unsigned)qin), "s"(lanes));
+            asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(q_hi) : "v"((unsigned)(qz >> 32)), "v"((unsigned)(qin >> 32)), "s"(lanes));
+            typedef const float __attribute__((address_space(1)))* gptr;     // global (not generic): global_load, not flat_load
+            const gptr q = (gptr)(((uint64_t)q_hi << 32) | q_lo);
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = q[j * 49];
         } else {
@@ -340,6 +347,17 @@ static inline int32_t gemm_autosplit(int M, int N, int K, int kb, int batch, LA 
     return launch_gemm_auto(M, N, K, kb, batch, splitk, la, lb, e, st);
 }
 
+// 8*49 zero floats, allocated once per process (the padding taps of ConvGatherB point here)
+static const float* conv_zeros() {
+    static const float* z = []() -> const float* {
+        float* p = nullptr;
+        if (hipMalloc(&p, sizeof(float) * 8 * 49) != hipSuccess) return nullptr;
+        if (hipMemset(p, 0, sizeof(float) * 8 * 49) != hipSuccess) return nullptr;
+        return p;
+    }();
+    return z;
+}
+
 }  // namespace arfe
 
 using namespace arfe;
@@ -460,7 +478,8 @@ extern "C" int32_t arfe_conv3x3_fwd(int32_t R, int32_t C, const float* x, int64_
     ARFE_CHECK_ARG(x && packed && y, ARFE_ERR_ARG, "conv3x3_fwd: null pointer");
     const float* wp = (const float*)packed;
     LoadRowMajorK la{wp, 0, (int64_t)C * C, C, C, C};     // A(m=co,k=ci) for tap kb
-    ConvGatherB lb{x, x_roi_stride, R * 49, C};
+    ConvGatherB lb{x, x_roi_stride, R * 49, C, conv_zeros()};
+    ARFE_CHECK_ARG(lb.zeros, ARFE_ERR_LAUNCH, "conv3x3: cannot allocate the padding block");
     EpiConv e{y, y_roi_stride, b, relu, nullptr, 0};
     return launch_gemm_auto(C, R * 49, C, 9, 1, 1, la, lb, e, as_stream(stream), /*exact=*/false, /*kb_inner=*/true);
 }
@@ -473,7 +492,8 @@ extern "C" int32_t arfe_conv3x3_bwd_data(int32_t R, int32_t C, const void* packe
     ARFE_CHECK_ARG(packed && dy && dx, ARFE_ERR_ARG, "conv3x3_bwd_data: null pointer");
     const float* wd = (const float*)packed + (size_t)9 * C * C;
     LoadRowMajorK la{wd, 0, (int64_t)C * C, C, C, C};      // A(m=ci,k=co) = w[co][ci][8-tap]
-    ConvGatherB lb{dy, dy_roi_stride, R * 49, C};
+    ConvGatherB lb{dy, dy_roi_stride, R * 49, C, conv_zeros()};
+    ARFE_CHECK_ARG(lb.zeros, ARFE_ERR_LAUNCH, "conv3x3: cannot allocate the padding block");
     EpiConv e{dx, dx_roi_stride, nullptr, 0, dx_mask, dx_mask_roi_stride};
     return launch_gemm_auto(C, R * 49, C, 9, 1, 1, la, lb, e, as_stream(stream), /*exact=*/false, /*kb_inner=*/true);
 }
