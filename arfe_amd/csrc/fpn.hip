@@ -102,6 +102,49 @@ __global__ __launch_bounds__(256) void fpn_gate_partial_kernel(Levels lv, TileTa
 
     for (int c0 = c_begin; c0 < c_end; c0 += GT_CC) {
         // ---- stage GT_CC channels x 18 rows x (64 + 2 halo) columns ----
+        if ((w & 3) == 0) {
+            // rows are whole 16-byte quads: clamped addresses + a select, so the 9 reads of a thread (and the halo
+            // read) are issued back to back instead of one per divergent branch
+            constexpr int NQ = GT_CC * (GT_H + 2) * 16 / 256;
+            static_assert(NQ * 256 == GT_CC * (GT_H + 2) * 16, "whole rounds");
+            float4_u v[NQ];
+#pragma unroll
+            for (int it = 0; it < NQ; ++it) {
+                const int q = tid + 256 * it;
+                const int cj = q & 15, rr = (q >> 4) % (GT_H + 2), cc = q / (16 * (GT_H + 2));
+                const int gy = ty0 - 1 + rr, gx = tx0 + 4 * cj, c = c0 + cc;
+                const bool ok = c < c_end && gy >= 0 && gy < h && gx < w;
+                const int cl = c < c_end ? c : c_end - 1, yl = gy < 0 ? 0 : (gy < h ? gy : h - 1), xl = gx < w ? gx : w - 4;
+                const float4_u t = *reinterpret_cast<const float4_u*>(xb + ((int64_t)cl * h + yl) * w + xl);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[it][e] = ok ? t[e] : 0.f;
+            }
+            float hv[2];
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int q = tid + 256 * it;
+                const int side = q & 1, rr = (q >> 1) % (GT_H + 2), cc = (q / (2 * (GT_H + 2))) % GT_CC;
+                const int gy = ty0 - 1 + rr, gx = side ? tx0 + GT_W : tx0 - 1, c = c0 + cc;
+                const bool ok = q < GT_CC * (GT_H + 2) * 2 && c < c_end && gy >= 0 && gy < h && gx >= 0 && gx < w;
+                const int cl = c < c_end ? c : c_end - 1, yl = gy < 0 ? 0 : (gy < h ? gy : h - 1), xl = gx < 0 ? 0 : (gx < w ? gx : w - 1);
+                const float t = xb[((int64_t)cl * h + yl) * w + xl];
+                hv[it] = ok ? t : 0.f;
+            }
+#pragma unroll
+            for (int it = 0; it < NQ; ++it) {
+                const int q = tid + 256 * it;
+                const int cj = q & 15, rr = (q >> 4) % (GT_H + 2), cc = q / (16 * (GT_H + 2));
+                *reinterpret_cast<float4*>(&tile[cc][rr][4 + 4 * cj]) = make_float4(v[it][0], v[it][1], v[it][2], v[it][3]);
+            }
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int q = tid + 256 * it;
+                if (q < GT_CC * (GT_H + 2) * 2) {
+                    const int side = q & 1, rr = (q >> 1) % (GT_H + 2), cc = q / (2 * (GT_H + 2));
+                    tile[cc][rr][side ? 4 + GT_W : 3] = hv[it];
+                }
+            }
+        } else {
         for (int q = tid; q < GT_CC * (GT_H + 2) * 16; q += 256) {
             const int cj = q & 15, rr = (q >> 4) % (GT_H + 2), cc = q / (16 * (GT_H + 2));
             const int gy = ty0 - 1 + rr, gx = tx0 + 4 * cj, c = c0 + cc;
@@ -122,6 +165,7 @@ __global__ __launch_bounds__(256) void fpn_gate_partial_kernel(Levels lv, TileTa
             float v = 0.f;
             if (c < c_end && gy >= 0 && gy < h && gx >= 0 && gx < w) v = xb[((int64_t)c * h + gy) * w + gx];
             tile[cc][rr][side ? 4 + GT_W : 3] = v;
+        }
         }
         if (tid < GT_CC * 18) {            // this chunk's conv weights (both maps) next to the tile
             const int cc = tid / 18, t = tid - cc * 18;
