@@ -405,7 +405,8 @@ static inline bool plan_large_tile(int M, int N, int batch, int ksteps, int* spl
     int sk = 1;
     if (*splitk > 1) {
         sk = (int)(256 / (tiles > 0 ? tiles : 1));
-        const int max_s = ksteps / 4 > 1 ? ksteps / 4 : 1;
+        const int max_s = ksteps / 8 > 1 ? ksteps / 8 : 1;   // >= 8 K-steps per slice: below that the 2-step pipeline
+                                                             // fill and the 256-KB atomic epilogue dominate (tools/gemm_sweep.py)
         if (sk > max_s) sk = max_s;
         if (sk < 1) sk = 1;
     }
