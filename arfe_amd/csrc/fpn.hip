@@ -67,163 +67,156 @@ __global__ __launch_bounds__(256) void fpn_gather_fwd_kernel(Levels lv, LevelPtr
 //   grid.x = spatial tiles of all levels, grid.y = channel group; partial pre-activations go to
 //   pre[group][2][pixel] and are finished (bias, ReLU, tanh) by gate_finish_kernel.
 // =========================================================================================================
-constexpr int GT_H = 16, GT_W = 64, GT_CC = 8, GT_LD = 72;
-constexpr int GATE_GROUPS = 4;
+// =========================================================================================================
+// Gate maps  a = tanh(relu(conv3x3(x; w1) + b1)),  b = ... (w2, b2)   (wfpn_dual_spatial.py: reduce_convs/2)
+// A 3x3 conv with ONE output channel is, per tap, a [pixels x C] . [C] product: all 18 (gate, tap) products of a pixel
+// are one row of   T[m=(gate,tap)][px] = sum_c W[m][c] * x[c][px]   -- an exact-fp32 MFMA GEMM with M = 18 (of 32),
+// N = pixels, K = C whose B operand (lane = pixel, 2 channels per instruction) is read straight from the NCHW map with
+// coalesced 128-B rows: x crosses the chip exactly once and no lane does per-tap index arithmetic.  The 9-tap
+// shift-add over T (18 one-channel maps) is the second, tiny kernel.
+// =========================================================================================================
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+constexpr int GM_TILES = 4;                  // 32-pixel MFMA tiles per wave
+constexpr int GM_WAVES = 2;                  // waves per workgroup (small workgroups: 700 of them balance over 256 CUs)
+constexpr int GM_PX = GM_WAVES * GM_TILES * 32;   // pixels per workgroup
+constexpr int GM_M = 18;                     // rows of T per image: 2 gates x 9 taps
+constexpr int GM_KC = 256;                   // channels whose weights are staged at a time (32 KB of LDS)
 
-struct TileTable {
-    int first_tile[NL_ + 1];   // prefix sum of tiles per level
-    int tiles_x[NL_], tiles_y[NL_];
+struct TileTable {             // name kept: the per-level pixel-chunk table of the gate kernels
+    int first_tile[NL_ + 1];   // prefix sum of workgroups per level
+    int tiles_x[NL_], tiles_y[NL_];   // tiles_x = chunks per image, tiles_y unused
     int64_t px_off[NL_ + 1];   // prefix sum of B*h*w (offset of a level inside a flattened per-pixel buffer)
 };
 
-__global__ __launch_bounds__(256) void fpn_gate_partial_kernel(Levels lv, TileTable tt, LevelPtrs x, LevelPtrs w1,
-                                                               LevelPtrs w2, float* __restrict__ pre, int64_t pre_total) {
-    __shared__ __attribute__((aligned(16))) float tile[GT_CC][GT_H + 2][GT_LD];
-    __shared__ float wsm[GT_CC][18];
+// Wp[level][channel][32]: row m = gate * 9 + tap of the A operand, zero for m >= 18 (so that staging it is a plain copy)
+__global__ void fpn_gate_pack_kernel(Levels lv, LevelPtrs w1, LevelPtrs w2, float* __restrict__ Wp) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= lv.n * lv.C * 32) return;
+    const int lvl = i / (lv.C * 32), rem = i - lvl * lv.C * 32, c = rem >> 5, m = rem & 31;
+    Wp[i] = m < 9 ? w1.p[lvl][c * 9 + m] : (m < GM_M ? w2.p[lvl][c * 9 + m - 9] : 0.f);
+}
+
+__global__ __launch_bounds__(64 * GM_WAVES) void fpn_gate_mfma_kernel(Levels lv, TileTable tt, LevelPtrs x,
+                                                                       const float* __restrict__ Wp, float* __restrict__ T) {
+    __shared__ __attribute__((aligned(16))) float Ws[GM_KC][32];            // [channel][m], m >= 18 zero
     int t = blockIdx.x, lvl = 0;
     while (lvl + 1 < lv.n && t >= tt.first_tile[lvl + 1]) ++lvl;
     t -= tt.first_tile[lvl];
-    const int h = lv.H[lvl], w = lv.W[lvl];
-    const int per_img = tt.tiles_x[lvl] * tt.tiles_y[lvl];
-    const int b = t / per_img;
-    t -= b * per_img;
-    const int ty0 = (t / tt.tiles_x[lvl]) * GT_H, tx0 = (t % tt.tiles_x[lvl]) * GT_W;
-    const int group = blockIdx.y;
-    const int cpg = (lv.C + GATE_GROUPS - 1) / GATE_GROUPS;
-    const int c_begin = group * cpg;
-    const int c_end = c_begin + cpg < lv.C ? c_begin + cpg : lv.C;
-
-    const int tid = threadIdx.x;
-    const int row = tid >> 4, j = tid & 15;        // output pixel (ty0+row, tx0+4j .. +3)
-    float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
-    const float* xb = x.p[lvl] + (int64_t)b * lv.C * h * w;
-    const float* W1 = w1.p[lvl];
-    const float* W2 = w2.p[lvl];
-
-    for (int c0 = c_begin; c0 < c_end; c0 += GT_CC) {
-        // ---- stage GT_CC channels x 18 rows x (64 + 2 halo) columns ----
-        if ((w & 3) == 0) {
-            // rows are whole 16-byte quads: clamped addresses + a select, so the 9 reads of a thread (and the halo
-            // read) are issued back to back instead of one per divergent branch
-            constexpr int NQ = GT_CC * (GT_H + 2) * 16 / 256;
-            static_assert(NQ * 256 == GT_CC * (GT_H + 2) * 16, "whole rounds");
-            float4_u v[NQ];
+    const int hw = lv.H[lvl] * lv.W[lvl];
+    const int bi = t / tt.tiles_x[lvl];
+    const int chunk = t - bi * tt.tiles_x[lvl];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const float* xb = x.p[lvl] + (int64_t)bi * lv.C * hw;
+    f32x16_t acc[GM_TILES];
 #pragma unroll
-            for (int it = 0; it < NQ; ++it) {
-                const int q = tid + 256 * it;
-                const int cj = q & 15, rr = (q >> 4) % (GT_H + 2), cc = q / (16 * (GT_H + 2));
-                const int gy = ty0 - 1 + rr, gx = tx0 + 4 * cj, c = c0 + cc;
-                const bool ok = c < c_end && gy >= 0 && gy < h && gx < w;
-                const int cl = c < c_end ? c : c_end - 1, yl = gy < 0 ? 0 : (gy < h ? gy : h - 1), xl = gx < w ? gx : w - 4;
-                const float4_u t = *reinterpret_cast<const float4_u*>(xb + ((int64_t)cl * h + yl) * w + xl);
+    for (int i = 0; i < GM_TILES; ++i)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[it][e] = ok ? t[e] : 0.f;
-            }
-            float hv[2];
-#pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                const int q = tid + 256 * it;
-                const int side = q & 1, rr = (q >> 1) % (GT_H + 2), cc = (q / (2 * (GT_H + 2))) % GT_CC;
-                const int gy = ty0 - 1 + rr, gx = side ? tx0 + GT_W : tx0 - 1, c = c0 + cc;
-                const bool ok = q < GT_CC * (GT_H + 2) * 2 && c < c_end && gy >= 0 && gy < h && gx >= 0 && gx < w;
-                const int cl = c < c_end ? c : c_end - 1, yl = gy < 0 ? 0 : (gy < h ? gy : h - 1), xl = gx < 0 ? 0 : (gx < w ? gx : w - 1);
-                const float t = xb[((int64_t)cl * h + yl) * w + xl];
-                hv[it] = ok ? t : 0.f;
-            }
-#pragma unroll
-            for (int it = 0; it < NQ; ++it) {
-                const int q = tid + 256 * it;
-                const int cj = q & 15, rr = (q >> 4) % (GT_H + 2), cc = q / (16 * (GT_H + 2));
-                *reinterpret_cast<float4*>(&tile[cc][rr][4 + 4 * cj]) = make_float4(v[it][0], v[it][1], v[it][2], v[it][3]);
-            }
-#pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                const int q = tid + 256 * it;
-                if (q < GT_CC * (GT_H + 2) * 2) {
-                    const int side = q & 1, rr = (q >> 1) % (GT_H + 2), cc = q / (2 * (GT_H + 2));
-                    tile[cc][rr][side ? 4 + GT_W : 3] = hv[it];
-                }
-            }
-        } else {
-        for (int q = tid; q < GT_CC * (GT_H + 2) * 16; q += 256) {
-            const int cj = q & 15, rr = (q >> 4) % (GT_H + 2), cc = q / (16 * (GT_H + 2));
-            const int gy = ty0 - 1 + rr, gx = tx0 + 4 * cj, c = c0 + cc;
-            float4_u v = {0.f, 0.f, 0.f, 0.f};
-            if (c < c_end && gy >= 0 && gy < h) {
-                const float* src = xb + ((int64_t)c * h + gy) * w + gx;
-                if (gx + 3 < w) v = *reinterpret_cast<const float4_u*>(src);
-                else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) if (gx + e < w) v[e] = src[e];
-                }
-            }
-            *reinterpret_cast<float4*>(&tile[cc][rr][4 + 4 * cj]) = make_float4(v[0], v[1], v[2], v[3]);
-        }
-        for (int q = tid; q < GT_CC * (GT_H + 2) * 2; q += 256) {
-            const int side = q & 1, rr = (q >> 1) % (GT_H + 2), cc = q / (2 * (GT_H + 2));
-            const int gy = ty0 - 1 + rr, gx = side ? tx0 + GT_W : tx0 - 1, c = c0 + cc;
-            float v = 0.f;
-            if (c < c_end && gy >= 0 && gy < h && gx >= 0 && gx < w) v = xb[((int64_t)c * h + gy) * w + gx];
-            tile[cc][rr][side ? 4 + GT_W : 3] = v;
-        }
-        }
-        if (tid < GT_CC * 18) {            // this chunk's conv weights (both maps) next to the tile
-            const int cc = tid / 18, t = tid - cc * 18;
-            const int c = c0 + cc;
-            wsm[cc][t] = c < c_end ? (t < 9 ? W1[c * 9 + t] : W2[c * 9 + t - 9]) : 0.f;
-        }
-        __syncthreads();
-        // ---- 18 taps x 4 px per channel ----
-#pragma unroll 2
-        for (int cc = 0; cc < GT_CC; ++cc) {
-            const int c = c0 + cc;
-            if (c >= c_end) break;
-            const float* k1 = &wsm[cc][0];
-            const float* k2 = &wsm[cc][9];
-#pragma unroll
-            for (int dy = 0; dy < 3; ++dy) {
-                const float* r = &tile[cc][row + dy][4 * j + 3];
-                const float4 mid = *reinterpret_cast<const float4*>(r + 1);
-                const float v[6] = {r[0], mid.x, mid.y, mid.z, mid.w, r[5]};
-                const float u0 = k1[dy * 3 + 0], u1 = k1[dy * 3 + 1], u2 = k1[dy * 3 + 2];
-                const float s0 = k2[dy * 3 + 0], s1 = k2[dy * 3 + 1], s2 = k2[dy * 3 + 2];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    a1[e] += u0 * v[e] + u1 * v[e + 1] + u2 * v[e + 2];
-                    a2[e] += s0 * v[e] + s1 * v[e + 1] + s2 * v[e + 2];
-                }
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    // The wave's four MFMA tiles interleave: tile i holds pixels p4 + i of every lane's quad p4 = ... + 4 * l31, so one
+    // 16-byte read per (channel pair, lane) feeds all four tiles (a dword read costs the address unit the same) and the
+    // four results of a row m go back as one 16-byte store.
+    const int p4 = chunk * GM_PX + wave * (GM_TILES * 32) + 4 * l31;
+    const bool quad_in = p4 + 3 < hw;                         // whole quad inside the map
+    const int pq = p4 < hw ? p4 : (hw - 1);                   // clamped start for the element-wise tail form
+    for (int c0 = 0; c0 < lv.C; c0 += GM_KC) {
+        if (c0) __syncthreads();
+        {
+            const int kc_ = lv.C - c0 < GM_KC ? lv.C - c0 : GM_KC;
+            const float4_u* src = reinterpret_cast<const float4_u*>(Wp + ((int64_t)lvl * lv.C + c0) * 32);
+            for (int i = tid; i < GM_KC * 8; i += 64 * GM_WAVES) {
+                float4_u v = {0.f, 0.f, 0.f, 0.f};
+                if (i < kc_ * 8) v = src[i];
+                *reinterpret_cast<float4_u*>(&Ws[0][0] + 4 * i) = v;
             }
         }
         __syncthreads();
+        if (chunk * GM_PX + wave * (GM_TILES * 32) >= hw) continue;          // wave-uniform: nothing of this wave is inside
+        const int kc = lv.C - c0 < GM_KC ? lv.C - c0 : GM_KC;
+        // three register sets of 4 channel pairs: the reads of groups g+1 and g+2 are out before the 16 MFMAs of group g
+        constexpr int GK = 4;
+        float a[3][GK];
+        float4_u b[3][GK];
+        auto issue = [&](int g, int set) {
+#pragma unroll
+            for (int j = 0; j < GK; ++j) {
+                const int k = 2 * (g * GK + j) + hh;
+                const int kw = k < GM_KC ? k : GM_KC - 1;
+                const int c = c0 + k < lv.C ? c0 + k : lv.C - 1;             // odd / short tails: the weight row is 0
+                a[set][j] = k < kc ? Ws[kw][l31] : 0.f;
+                const float* src = xb + (int64_t)c * hw;
+                if (quad_in) {
+                    b[set][j] = *reinterpret_cast<const float4_u*>(src + p4);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) b[set][j][e] = src[pq + e < hw ? pq + e : hw - 1];
+                }
+            }
+        };
+        auto mma = [&](int set) {
+#pragma unroll
+            for (int j = 0; j < GK; ++j)
+#pragma unroll
+                for (int i = 0; i < GM_TILES; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[set][j], b[set][j][i], acc[i], 0, 0, 0);
+        };
+        const int ngroups = ((kc + 1) / 2 + GK - 1) / GK;
+        issue(0, 0);
+        if (ngroups > 1) issue(1, 1);
+        for (int g = 0; g < ngroups; g += 3) {
+            if (g + 2 < ngroups) issue(g + 2, 2);
+            mma(0);
+            if (g + 1 < ngroups) {
+                if (g + 3 < ngroups) issue(g + 3, 0);
+                mma(1);
+            }
+            if (g + 2 < ngroups) {
+                if (g + 4 < ngroups) issue(g + 4, 1);
+                mma(2);
+            }
+        }
     }
-    const int oy = ty0 + row;
-    if (oy < h) {
-        float* p1 = pre + (int64_t)group * 2 * pre_total + tt.px_off[lvl] + ((int64_t)b * h + oy) * w;
-        float* p2 = p1 + pre_total;
+    // D layout: lane -> column l31 (here: quad p4); register r -> row m = (r & 3) + 8 * (r >> 2) + 4 * hh
+    float* Tb = T + tt.px_off[lvl] * GM_M + (int64_t)bi * GM_M * hw;
+    if (p4 < hw) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int ox = tx0 + 4 * j + e;
-            if (ox < w) { p1[ox] = a1[e]; p2[ox] = a2[e]; }
+        for (int r = 0; r < 12; ++r) {
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * hh;
+            if (m >= GM_M) continue;
+            float* dst = Tb + (int64_t)m * hw + p4;
+            if (quad_in) {
+                float4_u v = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+                *reinterpret_cast<float4_u*>(dst) = v;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (p4 + e < hw) dst[e] = acc[e][r];
+            }
         }
     }
 }
 
-// a = tanh(relu(sum_groups pre + bias))
-__global__ void fpn_gate_finish_kernel(Levels lv, TileTable tt, const float* __restrict__ pre, int64_t pre_total,
+// a[y][x] = tanh(relu(b1 + sum_tap T[tap][y+dy][x+dx])) with zero padding (tap = 3*(dy+1) + (dx+1)); same for b
+__global__ void fpn_gate_finish_kernel(Levels lv, TileTable tt, const float* __restrict__ T, int64_t pre_total,
                                        LevelPtrs b1, LevelPtrs b2, LevelMutPtrs a, LevelMutPtrs b) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= pre_total) return;
     int lvl = 0;
     while (lvl + 1 < lv.n && i >= tt.px_off[lvl + 1]) ++lvl;
+    const int h = lv.H[lvl], w = lv.W[lvl], hw = h * w;
+    const int64_t o = i - tt.px_off[lvl];
+    const int bi = (int)(o / hw), p = (int)(o - (int64_t)bi * hw), y = p / w, xx = p - y * w;
+    const float* Tb = T + tt.px_off[lvl] * GM_M + (int64_t)bi * GM_M * hw;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int g = 0; g < GATE_GROUPS; ++g) {
-        s1 += pre[(int64_t)g * 2 * pre_total + i];
-        s2 += pre[(int64_t)g * 2 * pre_total + pre_total + i];
+    for (int tap = 0; tap < 9; ++tap) {
+        const int yy = y + tap / 3 - 1, xs = xx + tap % 3 - 1;
+        const bool ok = yy >= 0 && yy < h && xs >= 0 && xs < w;
+        const int q = ok ? yy * w + xs : p;
+        const float v1 = Tb[(int64_t)tap * hw + q], v2 = Tb[(int64_t)(9 + tap) * hw + q];
+        s1 += ok ? v1 : 0.f;
+        s2 += ok ? v2 : 0.f;
     }
     s1 += b1.p[lvl][0];
     s2 += b2.p[lvl][0];
-    const int64_t o = i - tt.px_off[lvl];
     a.p[lvl][o] = tanhf(fmaxf(s1, 0.f));
     b.p[lvl][o] = tanhf(fmaxf(s2, 0.f));
 }
@@ -782,22 +775,18 @@ static TileTable make_tile_table(const Levels& lv) {
     int acc = 0;
     int64_t px = 0;
     for (int i = 0; i < NL_; ++i) {
+        tt.tiles_x[i] = tt.tiles_y[i] = 0;
+        tt.first_tile[i] = acc;
+        tt.px_off[i] = px;
         if (i < lv.n) {
-            tt.tiles_x[i] = cdiv(lv.W[i], GT_W);
-            tt.tiles_y[i] = cdiv(lv.H[i], GT_H);
-            tt.first_tile[i] = acc;
-            tt.px_off[i] = px;
-            acc += tt.tiles_x[i] * tt.tiles_y[i] * lv.B;
+            tt.tiles_x[i] = cdiv(lv.H[i] * lv.W[i], GM_PX);
+            tt.tiles_y[i] = 1;
+            acc += tt.tiles_x[i] * lv.B;
             px += (int64_t)lv.B * lv.H[i] * lv.W[i];
-        } else {
-            tt.tiles_x[i] = tt.tiles_y[i] = 0;
-            tt.first_tile[i] = acc;
-            tt.px_off[i] = px;
         }
     }
     tt.first_tile[NL_] = acc;
     tt.px_off[NL_] = px;
-    for (int i = lv.n; i <= NL_; ++i) { tt.first_tile[i] = acc; tt.px_off[i] = px; }
     return tt;
 }
 static QuadTable make_quad_table(const Levels& lv) {
@@ -843,7 +832,7 @@ extern "C" int64_t arfe_fpn_gatemap_workspace_bytes(const arfe_pyramid_t* pyr) {
     if (check_pyramid(pyr)) return -1;
     int64_t px = 0;
     for (int i = 0; i < pyr->num_levels; ++i) px += (int64_t)pyr->batch * pyr->height[i] * pyr->width[i];
-    return (int64_t)GATE_GROUPS * 2 * px * (int64_t)sizeof(float);
+    return ((int64_t)GM_M * px + (int64_t)pyr->num_levels * pyr->channels * 32) * (int64_t)sizeof(float);
 }
 
 extern "C" int32_t arfe_fpn_gather_fwd(const arfe_pyramid_t* pyr, const float* const* x, float* m, int32_t* argmax,
@@ -876,8 +865,11 @@ extern "C" int32_t arfe_fpn_gatemap_fwd(const arfe_pyramid_t* pyr, const float* 
     const int64_t pre_total = tt.px_off[lv.n];
     float* pre = (float*)workspace;
     hipStream_t st = as_stream(stream);
-    hipLaunchKernelGGL(fpn_gate_partial_kernel, dim3(tt.first_tile[lv.n], GATE_GROUPS), dim3(256), 0, st, lv, tt, xp, w1p,
-                       w2p, pre, pre_total);
+    float* Wp = pre + GM_M * pre_total;
+    hipLaunchKernelGGL(fpn_gate_pack_kernel, dim3(cdiv(lv.n * lv.C * 32, 256)), dim3(256), 0, st, lv, w1p, w2p, Wp);
+    ARFE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(fpn_gate_mfma_kernel, dim3(tt.first_tile[lv.n]), dim3(64 * GM_WAVES), 0, st, lv, tt, xp,
+                       (const float*)Wp, pre);
     ARFE_CHECK_LAUNCH();
     hipLaunchKernelGGL(fpn_gate_finish_kernel, dim3((unsigned)cdiv64(pre_total, 256)), dim3(256), 0, st, lv, tt, pre,
                        pre_total, b1p, b2p, ap, bp);

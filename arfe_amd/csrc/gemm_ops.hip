@@ -182,10 +182,15 @@ __global__ void reduce_mid_kernel(const float* __restrict__ x, const float* __re
     int o0 = blockIdx.y * outer_chunk;
     int o1 = o0 + outer_chunk < outer ? o0 + outer_chunk : outer;
     float s = 0.f;
-    for (int o = o0; o < o1; ++o) {
+    // short rows (the 49 pixels of an RoI channel): one wave per row, four rows in flight per workgroup; long rows
+    // (NonLocal, inner = L): the whole workgroup along the row
+    const bool short_rows = inner <= 64;
+    const int ostep = short_rows ? (int)(blockDim.x >> 6) : 1, istep = short_rows ? 64 : (int)blockDim.x;
+    const int ofirst = short_rows ? (int)(threadIdx.x >> 6) : 0, ifirst = short_rows ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
+    for (int o = o0 + ofirst; o < o1; o += ostep) {
         const float* row = x + (int64_t)o * outer_stride + (int64_t)mid * inner;
         const float* mrow = mask ? mask + (int64_t)o * outer_stride + (int64_t)mid * inner : nullptr;
-        for (int i = threadIdx.x; i < inner; i += blockDim.x) {
+        for (int i = ifirst; i < inner; i += istep) {
             float v = row[i];
             if (mrow && !(mrow[i] > 0.f)) v = 0.f;
             s += v;
