@@ -675,102 +675,138 @@ __global__ __launch_bounds__(256) void fpn_input_bwd_kernel(Levels lv, BlockQuad
 }
 
 // =========================================================================================================
-// gate-conv weight gradients: dw[c,ky,kx] = sum_{b,y,x} x[c, y+ky-1, x+kx-1] * dpre[y,x]
-//   one workgroup per (channel, level) walks every image plane in pixel quads: 5 row reads of x (16 B + 2 halo
-//   scalars each, the row above/below come from L1/L2) and two 16-B map reads feed 72 FMAs; the 18 (+2 bias)
-//   accumulators are reduced once per workgroup, so results are written without atomics.
+// gate-conv weight gradients: dw[g][c][tap] = sum_{b,y,x} x[c][y][x] * dpre_g[y - dy(tap)][x - dx(tap)]
+//   = (D [18 x pixels]) . (X^T [pixels x C]) with D[m=(g,tap)][px] the shifted, zero-padded gate gradient: an
+//   exact-fp32 MFMA GEMM whose K runs over pixels.  K is the contiguous axis of both operands, so a stage of 32 pixels
+//   goes through LDS: X rows are read with coalesced 16-byte loads (x crosses the chip once), D is built per stage
+//   (3 entries per thread), and the MFMA operands are then fetched k-major from the padded images.  One workgroup =
+//   256 pixels of one image x 256 channels (4 waves x 2 channel tiles); partial sums are added atomically (18 per channel).
 // =========================================================================================================
-constexpr int WG_ZSPLIT = 8;       // row slices per image plane (more workgroups in flight; partial sums add atomically)
+constexpr int GW_PX = 32, GW_STAGES = 8, GW_LD = 36, GW_CH = 256;
 __global__ void fpn_gate_wgrad_zero_kernel(int C, int n, LevelMutPtrs dw1, LevelMutPtrs db1, LevelMutPtrs dw2, LevelMutPtrs db2) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int per = 9 * C;
     if (i < n * per) { const int l = i / per, j = i - l * per; dw1.p[l][j] = 0.f; dw2.p[l][j] = 0.f; }
     if (i < n) { db1.p[i][0] = 0.f; db2.p[i][0] = 0.f; }
 }
-__global__ __launch_bounds__(256) void fpn_gate_wgrad_kernel(Levels lv, LevelPtrs x, LevelPtrs dpa, LevelPtrs dpb,
-                                                             LevelMutPtrs dw1, LevelMutPtrs db1, LevelMutPtrs dw2,
-                                                             LevelMutPtrs db2) {
-    const int c = blockIdx.x, lvl = blockIdx.y;
-    const int h = lv.H[lvl], w = lv.W[lvl], wq = (w + 3) >> 2;
-    const int bi = blockIdx.z / WG_ZSPLIT, zs = blockIdx.z - bi * WG_ZSPLIT;
-    const int rows_per = (h + WG_ZSPLIT - 1) / WG_ZSPLIT;
-    const int y_begin = zs * rows_per;
-    const int y_end = y_begin + rows_per < h ? y_begin + rows_per : h;
-    if (y_begin >= y_end) return;
-    float s1[9], s2[9], sa = 0.f, sb = 0.f;
+__global__ __launch_bounds__(256) void fpn_gate_wgrad_mfma_kernel(Levels lv, TileTable tt, LevelPtrs x, LevelPtrs dpa,
+                                                                  LevelPtrs dpb, LevelMutPtrs dw1, LevelMutPtrs db1,
+                                                                  LevelMutPtrs dw2, LevelMutPtrs db2) {
+    __shared__ __attribute__((aligned(16))) float Xs[GW_CH][GW_LD];
+    __shared__ float Ds[32][GW_LD];
+    int t = blockIdx.x, lvl = 0;
+    while (lvl + 1 < lv.n && t >= tt.first_tile[lvl + 1]) ++lvl;
+    t -= tt.first_tile[lvl];
+    const int h = lv.H[lvl], w = lv.W[lvl], hw = h * w;
+    const int bi = t / tt.tiles_x[lvl];
+    const int chunk = t - bi * tt.tiles_x[lvl];
+    const int cg0 = blockIdx.y * GW_CH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const float* xb = x.p[lvl] + (int64_t)bi * lv.C * hw;
+    const float* da = dpa.p[lvl] + (int64_t)bi * hw;
+    const float* db = dpb.p[lvl] + (int64_t)bi * hw;
+    const int px_begin = chunk * (GW_PX * GW_STAGES);
+    int nst = (hw - px_begin + GW_PX - 1) / GW_PX;
+    if (nst > GW_STAGES) nst = GW_STAGES;
+
+    for (int i = tid; i < 32 * GW_LD; i += 256) (&Ds[0][0])[i] = 0.f;       // rows 18..31 stay zero
+    f32x16_t acc[2];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) { s1[t] = 0.f; s2[t] = 0.f; }
-    const int nq = (y_end - y_begin) * wq;
-    {
-        const float* xp = x.p[lvl] + ((int64_t)bi * lv.C + c) * h * w;
-        const float* da = dpa.p[lvl] + (int64_t)bi * h * w;
-        const float* db = dpb.p[lvl] + (int64_t)bi * h * w;
-        for (int q = threadIdx.x; q < nq; q += 256) {
-            const int yl = q / wq;
-            const int y = y_begin + yl, x0 = (q - yl * wq) << 2;
-            float a4[4], b4[4];
-            if (x0 + 3 < w) {
-                const float4_u av = *reinterpret_cast<const float4_u*>(da + (int64_t)y * w + x0);
-                const float4_u bv = *reinterpret_cast<const float4_u*>(db + (int64_t)y * w + x0);
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { a4[e] = av[e]; b4[e] = bv[e]; }
-            } else {
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    // X staging: pass p covers channels cg0 + 32 p .. + 31, a thread reads quad (tid & 7) of channel row (tid >> 3)
+    const int xq = tid & 7, xc = tid >> 3;
+    float4_u xr[8];
+    auto load_x = [&](int stage) {
+        const int p = px_begin + stage * GW_PX + 4 * xq;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const bool ok = x0 + e < w;
-                    a4[e] = ok ? da[(int64_t)y * w + x0 + e] : 0.f;
-                    b4[e] = ok ? db[(int64_t)y * w + x0 + e] : 0.f;
-                }
+        for (int ps = 0; ps < 8; ++ps) {
+            const int c = cg0 + ps * 32 + xc;
+            const float* src = xb + (int64_t)(c < lv.C ? c : lv.C - 1) * hw;
+            if (p + 3 < hw) {
+                xr[ps] = *reinterpret_cast<const float4_u*>(src + p);
+            } else {       // the map's last pixels: clamped element reads (their D entries are zero)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xr[ps][e] = src[p + e < hw ? p + e : hw - 1];
             }
-            if (c == 0) { sa += (a4[0] + a4[1]) + (a4[2] + a4[3]); sb += (b4[0] + b4[1]) + (b4[2] + b4[3]); }
+        }
+    };
+    // D staging: thread -> pixel (tid & 31) of the stage, rows m = (tid >> 5) + 8 j
+    const int dpx = tid & 31, dmg = tid >> 5;
+    float sa = 0.f, sb = 0.f;
+    load_x(0);
+    for (int stage = 0; stage < nst; ++stage) {
+        if (stage) __syncthreads();                 // the previous stage's operand reads are done
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const int yy = y + ky - 1;
-                if (yy < 0 || yy >= h) continue;
-                const float* row = xp + (int64_t)yy * w;
-                float v[6];
-                v[0] = x0 > 0 ? row[x0 - 1] : 0.f;
-                if (x0 + 4 < w) {
-                    const float4_u m = *reinterpret_cast<const float4_u*>(row + x0);
-                    v[1] = m[0]; v[2] = m[1]; v[3] = m[2]; v[4] = m[3];
-                    v[5] = row[x0 + 4];
-                } else {
+        for (int ps = 0; ps < 8; ++ps) *reinterpret_cast<float4_u*>(&Xs[ps * 32 + xc][4 * xq]) = xr[ps];
+        {
+            const int p = px_begin + stage * GW_PX + dpx;
+            const bool valid = p < hw;
+            const int pc = valid ? p : hw - 1;
+            const int y = pc / w, xx = pc - y * w;
 #pragma unroll
-                    for (int e = 0; e < 5; ++e) v[1 + e] = x0 + e < w ? row[x0 + e] : 0.f;
-                }
+            for (int j = 0; j < 3; ++j) {
+                const int m = dmg + 8 * j;
+                if (m >= GM_M) continue;
+                const int g = m >= 9 ? 1 : 0, tap = m - 9 * g;
+                const int yy = y - (tap / 3 - 1), xs = xx - (tap % 3 - 1);
+                const bool ok = valid && yy >= 0 && yy < h && xs >= 0 && xs < w;
+                const float v0 = (g ? db : da)[ok ? yy * w + xs : pc];
+                const float v = ok ? v0 : 0.f;
+                Ds[m][dpx] = v;
+                if (m == 4) sa += v;
+                if (m == 13) sb += v;
+            }
+        }
+        __syncthreads();
+        if (stage + 1 < nst) load_x(stage + 1);     // in flight during the MFMAs
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx)
+        for (int s2 = 0; s2 < GW_PX / 2; ++s2) {
+            const float a = Ds[l31][2 * s2 + hh];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        s1[ky * 3 + kx] += v[e + kx] * a4[e];
-                        s2[ky * 3 + kx] += v[e + kx] * b4[e];
-                    }
+            for (int nt = 0; nt < 2; ++nt) {
+                const float b = Xs[wave * 64 + nt * 32 + l31][2 * s2 + hh];
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[nt], 0, 0, 0);
             }
         }
     }
-    __shared__ float red[4][20];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // D layout: lane -> column l31 (channel); register r -> row m = (r & 3) + 8 * (r >> 2) + 4 * hh.
+    // The sums go through LDS into the [channel][tap] order of dw, so that every atomic wave-instruction adds 256
+    // contiguous bytes (lane stride 36 B, one value per channel row, runs an order of magnitude slower at the memory side).
+    __syncthreads();                                  // all operand reads of the last stage are done: Xs is free
+    float* Ts = &Xs[0][0] + wave * (2 * 64 * 9);      // [gate][64 channels of this wave][9]
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const float v1 = wave_sum(s1[t]), v2 = wave_sum(s2[t]);
-        if (lane == 0) { red[wv][t] = v1; red[wv][9 + t] = v2; }
-    }
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 12; ++r) {
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * hh;
+            if (m >= GM_M) continue;
+            const int g = m >= 9 ? 1 : 0;
+            Ts[(g * 64 + nt * 32 + l31) * 9 + (m - 9 * g)] = acc[nt][r];
+        }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
     {
-        const float v1 = wave_sum(sa), v2 = wave_sum(sb);
-        if (lane == 0) { red[wv][18] = v1; red[wv][19] = v2; }
+        const int cw0 = cg0 + wave * 64;
+        const int nch = lv.C - cw0 < 64 ? lv.C - cw0 : 64;
+        for (int i = lane; i < nch * 9; i += 64) {
+            unsafeAtomicAdd(dw1.p[lvl] + cw0 * 9 + i, Ts[i]);
+            unsafeAtomicAdd(dw2.p[lvl] + cw0 * 9 + i, Ts[64 * 9 + i]);
+        }
     }
-    __syncthreads();
-    if (threadIdx.x < 20) {
-        const int t = threadIdx.x;
-        const float v = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
-        if (t < 9) unsafeAtomicAdd(dw1.p[lvl] + c * 9 + t, v);
-        else if (t < 18) unsafeAtomicAdd(dw2.p[lvl] + c * 9 + (t - 9), v);
-        else if (c == 0) unsafeAtomicAdd(t == 18 ? db1.p[lvl] : db2.p[lvl], v);
+    if (blockIdx.y == 0) {          // bias gradients = plain sums of the two maps (the centre taps of D)
+        const float v1 = wave_sum(sa), v2 = wave_sum(sb);
+        if (lane == 0) {
+            if (v1 != 0.f) unsafeAtomicAdd(db1.p[lvl], v1);
+            if (v2 != 0.f) unsafeAtomicAdd(db2.p[lvl], v2);
+        }
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------
-static TileTable make_tile_table(const Levels& lv) {
+static TileTable make_tile_table(const Levels& lv, int chunk_px = GM_PX) {
     TileTable tt;
     int acc = 0;
     int64_t px = 0;
@@ -779,7 +815,7 @@ static TileTable make_tile_table(const Levels& lv) {
         tt.first_tile[i] = acc;
         tt.px_off[i] = px;
         if (i < lv.n) {
-            tt.tiles_x[i] = cdiv(lv.H[i] * lv.W[i], GM_PX);
+            tt.tiles_x[i] = cdiv(lv.H[i] * lv.W[i], chunk_px);
             tt.tiles_y[i] = 1;
             acc += tt.tiles_x[i] * lv.B;
             px += (int64_t)lv.B * lv.H[i] * lv.W[i];
@@ -978,8 +1014,9 @@ extern "C" int32_t arfe_fpn_gate_wgrad(const arfe_pyramid_t* pyr, const float* c
     hipLaunchKernelGGL(fpn_gate_wgrad_zero_kernel, dim3(cdiv(lv.n * 9 * lv.C, 256)), dim3(256), 0, as_stream(stream), lv.C,
                        lv.n, w1p, b1p, w2p, b2p);
     ARFE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(fpn_gate_wgrad_kernel, dim3(lv.C, lv.n, lv.B * WG_ZSPLIT), dim3(256), 0, as_stream(stream), lv, xp,
-                       dap, dbp, w1p, b1p, w2p, b2p);
+    TileTable tt = make_tile_table(lv, GW_PX * GW_STAGES);
+    hipLaunchKernelGGL(fpn_gate_wgrad_mfma_kernel, dim3(tt.first_tile[lv.n], cdiv(lv.C, GW_CH)), dim3(256), 0,
+                       as_stream(stream), lv, tt, xp, dap, dbp, w1p, b1p, w2p, b2p);
     ARFE_CHECK_LAUNCH();
     return ARFE_OK;
 }
