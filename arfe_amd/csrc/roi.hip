@@ -433,7 +433,7 @@ __global__ __launch_bounds__(256) void roialign_bwd_tiles_kernel(RoiLevels L, Ro
                                                                  const RoiWeightHdr* __restrict__ hdr,
                                                                  const float* __restrict__ wtab, int ntiles, int nchunks) {
     __shared__ __attribute__((aligned(16))) float G_s[RB_NB][RB_CC][7][8];       // [roi][c][ph][pw (+1 pad)]
-    __shared__ __attribute__((aligned(16))) float T_s[RB_NB][7][RB_CC / 4][RT][4];  // [roi][ph][c/4][x][c%4]
+    __shared__ float T_s[RB_CC][8][RT];                                          // [c][ph (row 7 = 0)][x], one RoI at a time
     __shared__ __attribute__((aligned(16))) float wy_s[RB_NB][RT][8], wx_s[RB_NB][RT][8];
     // coarse levels hold few tiles with long RoI lists: dispatch them first (reverse tile order) and cut a long
     // list into RB_SEGS slices handled by different workgroups (those add atomically into the zeroed output)
@@ -456,9 +456,18 @@ __global__ __launch_bounds__(256) void roialign_bwd_tiles_kernel(RoiLevels L, Ro
     const int ncc = L.C - c0 < RB_CC ? L.C - c0 : RB_CC;
     const int tid = threadIdx.x, py = tid >> 4, px = tid & 15;
     const int y = ty * RT + py, x = tx * RT + px;
-    float acc[RB_CC];
+    // Both contractions run on the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32).  Wave v owns channels 4v..4v+3 of the chunk:
+    //   C: T[(c,ph)][x] = sum_pw G[(c,ph)][pw] wx[pw][x]   (two channels = 14 of the 16 rows of one M tile, K = 8)
+    //   D: dX_c[y][x] += sum_ph wy[y][ph] T_c[ph][x]        (accumulated over the RoIs of the list in the MFMA D tile)
+    // D tile layout: lane l holds rows 4*(l/16)+r, r = 0..3, of column l%16.
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    const int lane = tid & 63, wv = tid >> 6, l15 = lane & 15, lq = lane >> 4;
+    f32x4_t acc[4];
 #pragma unroll
-    for (int c = 0; c < RB_CC; ++c) acc[c] = 0.f;
+    for (int c = 0; c < 4; ++c) acc[c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    // pad lanes of the k = 8 contractions (bin 7) are never written by the staging below: zero them once
+    for (int i = tid; i < RB_NB * RT; i += 256) { wy_s[i / RT][i % RT][7] = 0.f; wx_s[i / RT][i % RT][7] = 0.f; }
+    for (int i = tid; i < RB_NB * RB_CC * 7; i += 256) G_s[i / (RB_CC * 7)][(i / 7) % RB_CC][i % 7][7] = 0.f;
 
     const int per_seg = (lend - lbeg + nseg - 1) / nseg;
     const int beg = lbeg + seg * per_seg;
@@ -472,6 +481,12 @@ __global__ __launch_bounds__(256) void roialign_bwd_tiles_kernel(RoiLevels L, Ro
     // register prefetch of one batch: the dependent global reads (list -> header -> table, gradients) of batch n+1
     // are in flight while batch n is contracted
     float pw[RB_NB], pg[RB_NB][RB_GPT];
+    // software pipeline of the dependent reads: RoI ids two batches ahead, header -> table / gradients one batch ahead
+    int ids[RB_NB];
+    auto fetch_ids = [&](int e0) {
+#pragma unroll
+        for (int j = 0; j < RB_NB; ++j) ids[j] = e0 + j < end ? list[e0 + j] : 0;
+    };
     auto prefetch = [&](int e0) {
         const int nb = end - e0 < RB_NB ? end - e0 : RB_NB;
 #pragma unroll
@@ -480,7 +495,7 @@ __global__ __launch_bounds__(256) void roialign_bwd_tiles_kernel(RoiLevels L, Ro
 #pragma unroll
             for (int i = 0; i < RB_GPT; ++i) pg[j][i] = 0.f;
             if (j >= nb) continue;
-            const int id = list[e0 + j];
+            const int id = ids[j];
             const int s = id / S.R, k = id - s * S.R;
             if (a_role) {
                 const RoiWeightHdr* hp = hdr + id;
@@ -504,7 +519,7 @@ __global__ __launch_bounds__(256) void roialign_bwd_tiles_kernel(RoiLevels L, Ro
             }
         }
     };
-    if (beg < end) prefetch(beg);
+    if (beg < end) { fetch_ids(beg); prefetch(beg); fetch_ids(beg + RB_NB); }
     for (int e0 = beg; e0 < end; e0 += RB_NB) {
         const int nb = end - e0 < RB_NB ? end - e0 : RB_NB;
         __syncthreads();                       // previous batch's LDS reads are done
@@ -522,58 +537,54 @@ __global__ __launch_bounds__(256) void roialign_bwd_tiles_kernel(RoiLevels L, Ro
             }
         }
         __syncthreads();
-        if (e0 + RB_NB < end) prefetch(e0 + RB_NB);
-        // ---- C: column contraction T[ph][x][c] = sum_pw wx[x][pw] G[c][ph][pw] ----
-        if (grp < ncc) {
-            for (int j = 0; j < nb; ++j) {
-                const float4 w0 = *reinterpret_cast<const float4*>(&wx_s[j][px][0]);
-                const float4 w1 = *reinterpret_cast<const float4*>(&wx_s[j][px][4]);
-#pragma unroll
-                for (int ph = 0; ph < 7; ++ph) {
-                    const float4 g0 = *reinterpret_cast<const float4*>(&G_s[j][grp][ph][0]);
-                    const float4 g1 = *reinterpret_cast<const float4*>(&G_s[j][grp][ph][4]);
-                    T_s[j][ph][grp >> 2][px][grp & 3] = w0.x * g0.x + w0.y * g0.y + w0.z * g0.z + w0.w * g0.w + w1.x * g1.x +
-                                                        w1.y * g1.y + w1.z * g1.z;
-                }
-            }
-        }
-        __syncthreads();
-        // ---- D: row contraction into the pixel accumulators (4 channels per LDS read) ----
+        if (e0 + RB_NB < end) { prefetch(e0 + RB_NB); fetch_ids(e0 + 2 * RB_NB); }
+        // ---- C then D per RoI (per wave, its own 4 channels: no workgroup barrier, T_s rows are private to the wave) ----
         for (int j = 0; j < nb; ++j) {
-            const float4 y0v = *reinterpret_cast<const float4*>(&wy_s[j][py][0]);
-            const float4 y1v = *reinterpret_cast<const float4*>(&wy_s[j][py][4]);
-            const float wy[7] = {y0v.x, y0v.y, y0v.z, y0v.w, y1v.x, y1v.y, y1v.z};
-            unsigned mask = 0;
 #pragma unroll
-            for (int t = 0; t < 7; ++t) mask |= (__any(wy[t] != 0.f) ? 1u : 0u) << t;
-            if (mask == 0) continue;
+            for (int pr = 0; pr < 2; ++pr) {
+                const int cl = wv * 4 + pr * 2 + (l15 >> 3), ph = l15 & 7;      // A row l15 -> (channel, bin)
+                f32x4_t t = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ph = 0; ph < 7; ++ph) {
-                if (!(mask & (1u << ph))) continue;
-#pragma unroll
-                for (int c4 = 0; c4 < RB_CC / 4; ++c4) {
-                    const float4 t = *reinterpret_cast<const float4*>(&T_s[j][ph][c4][px][0]);
-                    acc[4 * c4 + 0] += wy[ph] * t.x;
-                    acc[4 * c4 + 1] += wy[ph] * t.y;
-                    acc[4 * c4 + 2] += wy[ph] * t.z;
-                    acc[4 * c4 + 3] += wy[ph] * t.w;
+                for (int kk = 0; kk < 2; ++kk) {
+                    const float a = ph < 7 ? G_s[j][cl][ph < 7 ? ph : 6][4 * kk + lq] : 0.f;
+                    const float b = wx_s[j][l15][4 * kk + lq];
+                    t = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, t, 0, 0, 0);
                 }
+                // rows 4*lq + r of the M tile = (channel 4v + 2pr + (lq >> 1), bin 4*(lq & 1) + r), column l15
+                float* dst = &T_s[wv * 4 + pr * 2 + (lq >> 1)][4 * (lq & 1)][l15];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[r * RT] = t[r];
             }
+            const float a0 = wy_s[j][l15][lq], a1 = wy_s[j][l15][4 + lq];
+            __builtin_amdgcn_s_waitcnt(0xc07f);     // lgkmcnt(0): this wave's T rows have landed
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float b0 = T_s[wv * 4 + c][lq][l15], b1 = T_s[wv * 4 + c][4 + lq][l15];
+                acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[c], 0, 0, 0);
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);     // T rows are read before the next RoI overwrites them
+            __builtin_amdgcn_wave_barrier();
         }
     }
-    if (y < H && x < W) {
+    {
         float* d = L.dfeat[0];
 #pragma unroll
         for (int i = 1; i < ARFE_MAX_LEVELS; ++i) if (i == lvl) d = L.dfeat[i];
-        d += (((int64_t)b * L.C + c0) * H + y) * W + x;
-        if (nseg == 1) {
+        const int ox = tx * RT + l15;
 #pragma unroll
-            for (int c = 0; c < RB_CC; ++c)
-                if (c < ncc) d[(int64_t)c * H * W] = acc[c];
-        } else {
+        for (int c = 0; c < 4; ++c) {
+            const int cc = wv * 4 + c;
+            if (cc >= ncc || ox >= W) continue;
 #pragma unroll
-            for (int c = 0; c < RB_CC; ++c)
-                if (c < ncc) unsafeAtomicAdd(d + (int64_t)c * H * W, acc[c]);
+            for (int r = 0; r < 4; ++r) {
+                const int oy = ty * RT + 4 * lq + r;
+                if (oy >= H) continue;
+                float* dst = d + (((int64_t)b * L.C + c0 + cc) * H + oy) * W + ox;
+                if (nseg == 1) *dst = acc[c][r];
+                else unsafeAtomicAdd(dst, acc[c][r]);
+            }
         }
     }
 }
