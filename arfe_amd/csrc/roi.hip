@@ -123,9 +123,17 @@ __device__ __forceinline__ bool axis_range(float start, float size, int n, int& 
     return true;
 }
 
+struct RoiWeightHdr {
+    int id, lvl, img;               // RoI (set * R + k) of this slot, its level and image
+    int y0, x0, big; float inv;
+    int hext, wext;                 // rows / columns of the window that carry weight
+    int ylo[7], yhi[7];             // row support [ylo, yhi) of bin ph (offsets into the table)
+    int xlo[7], xhi[7];             // column support of bin pw
+};
 template <bool FILL>
 __global__ void roi_bin_kernel(RoiLevels L, RoiSets S, RoiTileTable T, int P, int* __restrict__ counts,
-                               const int* __restrict__ offsets, int* __restrict__ cursors, int* __restrict__ list) {
+                               const int* __restrict__ offsets, int* __restrict__ cursors, int* __restrict__ list,
+                               const RoiWeightHdr* __restrict__ hdr, int* __restrict__ lmeta) {
     int id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= S.nsets * S.R) return;
     const int s = id / S.R, k = id - s * S.R;
@@ -140,12 +148,17 @@ __global__ void roi_bin_kernel(RoiLevels L, RoiSets S, RoiTileTable T, int P, in
     const float xe = roi[3] * scale - 0.5f, ye = roi[4] * scale - 0.5f;
     int y0, y1, x0, x1;
     if (!axis_range(ys, ye - ys, H, y0, y1) || !axis_range(xs, xe - xs, W, x0, x1)) return;
+    // the window origin and form of the weight table travel with the list entry, so that the tile kernel's reads of
+    // table and gradients depend on ONE earlier read (the entry), not on entry -> header -> table
+    int meta = 0;
+    if (FILL) meta = (hdr[id].big << 28) | ((hdr[id].y0 & 0x3fff) << 14) | (hdr[id].x0 & 0x3fff);
     for (int ty = y0 / RT; ty <= y1 / RT; ++ty)
         for (int tx = x0 / RT; tx <= x1 / RT; ++tx) {
             const int tile = T.first[lvl] + (b * T.tiles_y[lvl] + ty) * T.tiles_x[lvl] + tx;
             if (FILL) {
                 const int pos = atomicAdd(cursors + tile, 1);
                 list[offsets[tile] + pos] = id;
+                lmeta[offsets[tile] + pos] = meta;
             } else {
                 atomicAdd(counts + tile, 1);
             }
@@ -200,17 +213,10 @@ __device__ __forceinline__ float axis_weight(float start, float bin, int grid, i
 // The tile kernel then only copies its 16-row / 16-column slice instead of re-deriving the geometry per tile.
 constexpr int RW_EXT = 64;
 // big: 0 table valid, 1 window larger than the table (consumers compute on the fly), 2 no sample inside the map
-struct RoiWeightHdr {
-    int id, lvl, img;               // RoI (set * R + k) of this slot, its level and image
-    int y0, x0, big; float inv;
-    int hext, wext;                 // rows / columns of the window that carry weight
-    int ylo[7], yhi[7];             // row support [ylo, yhi) of bin ph (offsets into the table)
-    int xlo[7], xhi[7];             // column support of bin pw
-};
 
 __global__ __launch_bounds__(256) void roi_weight_table_kernel(RoiLevels L, RoiSets S, int P, int sample_num,
                                                                RoiWeightHdr* __restrict__ hdr, float* __restrict__ wtab,
-                                                               const int32_t* __restrict__ order) {
+                                                               const int32_t* __restrict__ order, int prescale_y) {
     __shared__ float w_s[2][7][RW_EXT];
     // slot blockIdx.x of the tables describes RoI order[slot] (forward: spatial processing order) or RoI slot itself
     const int slot = blockIdx.x;
@@ -238,6 +244,7 @@ __global__ __launch_bounds__(256) void roi_weight_table_kernel(RoiLevels L, RoiS
         float w = axis == 0 ? axis_weight(g.y_start, g.bin_h, g.grid_h, pb, H, y0 + off)
                             : axis_weight(g.x_start, g.bin_w, g.grid_w, pb, W, x0 + off);
         if ((axis == 0 ? y0 : x0) + off >= (axis == 0 ? H : W)) w = 0.f;
+        if (prescale_y && axis == 0) w *= 1.0f / (float)(g.grid_h * g.grid_w > 1 ? g.grid_h * g.grid_w : 1);   // = h->inv
         wt[i] = w;
         (&w_s[0][0][0])[i] = w;
     }
@@ -430,7 +437,7 @@ static_assert(RB_CC == 16 && RT == 16, "phase C maps the 16 lane-groups of a wor
 __global__ __launch_bounds__(256) void roialign_bwd_tiles_kernel(RoiLevels L, RoiSets S, RoiTileTable T, int P, int sample_num,
                                                                  const float* __restrict__ gout, int64_t g_roi_stride,
                                                                  const int* __restrict__ offsets, const int* __restrict__ list,
-                                                                 const RoiWeightHdr* __restrict__ hdr,
+                                                                 const int* __restrict__ lmeta,
                                                                  const float* __restrict__ wtab, int ntiles, int nchunks) {
     __shared__ __attribute__((aligned(16))) float G_s[RB_NB][RB_CC][7][8];       // [roi][c][ph][pw (+1 pad)]
     __shared__ float T_s[RB_CC][8][RT];                                          // [c][ph (row 7 = 0)][x], one RoI at a time
@@ -482,10 +489,13 @@ __global__ __launch_bounds__(256) void roialign_bwd_tiles_kernel(RoiLevels L, Ro
     // are in flight while batch n is contracted
     float pw[RB_NB], pg[RB_NB][RB_GPT];
     // software pipeline of the dependent reads: RoI ids two batches ahead, header -> table / gradients one batch ahead
-    int ids[RB_NB];
+    int ids[RB_NB], metas[RB_NB];
     auto fetch_ids = [&](int e0) {
 #pragma unroll
-        for (int j = 0; j < RB_NB; ++j) ids[j] = e0 + j < end ? list[e0 + j] : 0;
+        for (int j = 0; j < RB_NB; ++j) {
+            ids[j] = e0 + j < end ? list[e0 + j] : 0;
+            metas[j] = e0 + j < end ? lmeta[e0 + j] : 0;
+        }
     };
     auto prefetch = [&](int e0) {
         const int nb = end - e0 < RB_NB ? end - e0 : RB_NB;
@@ -498,18 +508,18 @@ __global__ __launch_bounds__(256) void roialign_bwd_tiles_kernel(RoiLevels L, Ro
             const int id = ids[j];
             const int s = id / S.R, k = id - s * S.R;
             if (a_role) {
-                const RoiWeightHdr* hp = hdr + id;
-                const int big = hp->big;
+                const int big = metas[j] >> 28, wy0 = (metas[j] >> 14) & 0x3fff, wx0 = metas[j] & 0x3fff;
                 float w;
-                if (big == 0) {
-                    const int off = (a_axis ? tx * RT - hp->x0 : ty * RT - hp->y0) + a_r;
+                if (big == 0) {          // table form (axis 0 already carries 1/samples)
+                    const int off = (a_axis ? tx * RT - wx0 : ty * RT - wy0) + a_r;
                     w = (off >= 0 && off < RW_EXT) ? wtab[((int64_t)id * 2 + a_axis) * 7 * RW_EXT + a_pb * RW_EXT + off] : 0.f;
                 } else {
                     const RoiGeom g = roi_geom(S.rois[s] + 5 * (int64_t)k, scale, P, sample_num);
                     w = a_axis ? axis_weight(g.x_start, g.bin_w, g.grid_w, a_pb, W, tx * RT + a_r)
-                               : axis_weight(g.y_start, g.bin_h, g.grid_h, a_pb, H, ty * RT + a_r);
+                               : axis_weight(g.y_start, g.bin_h, g.grid_h, a_pb, H, ty * RT + a_r) *
+                                     (1.0f / (float)(g.grid_h * g.grid_w > 1 ? g.grid_h * g.grid_w : 1));
                 }
-                pw[j] = a_axis ? w : w * hp->inv;
+                pw[j] = w;
             }
             const float* gp = gout + (int64_t)k * g_roi_stride + ((int64_t)s * L.C + c0) * 49;
 #pragma unroll
@@ -706,7 +716,7 @@ extern "C" int32_t arfe_roialign_fwd(const arfe_pyramid_t* pyr, const float* con
     hipLaunchKernelGGL(roi_rank_kernel, dim3(cdiv(nroi, 4)), dim3(256), 0, st, nroi, (const uint32_t*)keys, order);
     ARFE_CHECK_LAUNCH();
     hipLaunchKernelGGL(roi_weight_table_kernel, dim3(nroi), dim3(256), 0, st, L, S, pooled, sample_num, hdr, wtab,
-                       (const int32_t*)order);
+                       (const int32_t*)order, 0);
     ARFE_CHECK_LAUNCH();
     hipLaunchKernelGGL(roialign_fwd_sep_kernel, dim3(nroi * nslices), dim3(256), 0, st, L, S, pooled, sample_num,
                        (const RoiWeightHdr*)hdr, (const float*)wtab, nslices, out, out_roi_stride);
@@ -738,8 +748,8 @@ extern "C" int64_t arfe_roialign_bwd_workspace_bytes(const arfe_pyramid_t* pyr, 
     if (check_pyramid(pyr) || nsets < 1 || nsets > RB_MAXSETS || R < 0) return -1;
     int ntiles, mx;
     make_roi_tile_table(pyr, &ntiles, &mx);
-    // counts[ntiles] | offsets[ntiles+1] | cursors[ntiles] | list[nsets*R*mx] | hdr[nsets*R] | wtab[nsets*R][2][7][RW_EXT]
-    return ((int64_t)3 * ntiles + 1 + (int64_t)nsets * R * mx + 16) * (int64_t)sizeof(int) +
+    // counts[ntiles] | offsets[ntiles+1] | cursors[ntiles] | list, lmeta[nsets*R*mx] | hdr[nsets*R] | wtab[nsets*R][2][7][RW_EXT]
+    return ((int64_t)3 * ntiles + 1 + (int64_t)2 * nsets * R * mx + 16) * (int64_t)sizeof(int) +
            (int64_t)nsets * R * ((int64_t)sizeof(RoiWeightHdr) + (int64_t)2 * 7 * RW_EXT * sizeof(float)) + 64;
 }
 
@@ -769,7 +779,8 @@ extern "C" int32_t arfe_roialign_bwd(const arfe_pyramid_t* pyr, float* const* df
     int* cursors = offsets + ntiles + 1;
     int* list = cursors + ntiles;
     const int nroi_all = nsets * R;
-    uintptr_t after = (uintptr_t)(list + (size_t)nroi_all * mx);
+    int* lmeta = list + (size_t)nroi_all * mx;
+    uintptr_t after = (uintptr_t)(lmeta + (size_t)nroi_all * mx);
     after = (after + 15) & ~(uintptr_t)15;
     RoiWeightHdr* hdr = (RoiWeightHdr*)after;
     float* wtab = (float*)(hdr + nroi_all);
@@ -781,14 +792,17 @@ extern "C" int32_t arfe_roialign_bwd(const arfe_pyramid_t* pyr, float* const* df
     const int nroi = nsets * R;
     if (nroi > 0) {
         hipLaunchKernelGGL((roi_bin_kernel<false>), dim3(cdiv(nroi, 256)), dim3(256), 0, st, L, S, T, pooled, counts,
-                           (const int*)offsets, cursors, list);
+                           (const int*)offsets, cursors, list, (const RoiWeightHdr*)nullptr, (int*)nullptr);
+        ARFE_CHECK_LAUNCH();
+        hipLaunchKernelGGL(roi_weight_table_kernel, dim3(nroi), dim3(256), 0, st, L, S, pooled, sample_num, hdr, wtab,
+                           (const int32_t*)nullptr, 1);
         ARFE_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(roi_bin_scan_kernel, dim3(1), dim3(1024), 0, st, (const int*)counts, offsets, cursors, ntiles);
     ARFE_CHECK_LAUNCH();
     if (nroi > 0) {
         hipLaunchKernelGGL((roi_bin_kernel<true>), dim3(cdiv(nroi, 256)), dim3(256), 0, st, L, S, T, pooled, counts,
-                           (const int*)offsets, cursors, list);
+                           (const int*)offsets, cursors, list, (const RoiWeightHdr*)hdr, lmeta);
         ARFE_CHECK_LAUNCH();
     }
     for (int i = 0; i < L.n; ++i)      // tiles whose list is cut into slices accumulate atomically
@@ -796,15 +810,11 @@ extern "C" int32_t arfe_roialign_bwd(const arfe_pyramid_t* pyr, float* const* df
             set_error("roialign_bwd: memset failed");
             return ARFE_ERR_LAUNCH;
         }
-    if (nroi > 0) {
-        hipLaunchKernelGGL(roi_weight_table_kernel, dim3(nroi), dim3(256), 0, st, L, S, pooled, sample_num, hdr, wtab, (const int32_t*)nullptr);
-        ARFE_CHECK_LAUNCH();
-    }
     const int nchunks = cdiv(L.C, RB_CC);
     ARFE_CHECK_ARG((int64_t)ntiles * nchunks < (int64_t)1 << 31, ARFE_ERR_ARG, "roialign_bwd: pyramid too large");
     hipLaunchKernelGGL(roialign_bwd_tiles_kernel, dim3(ntiles * nchunks, 1, RB_SEGS), dim3(256), 0, st, L, S, T, pooled,
-                       sample_num, gout, gout_roi_stride, (const int*)offsets, (const int*)list,
-                       (const RoiWeightHdr*)hdr, (const float*)wtab, ntiles, nchunks);
+                       sample_num, gout, gout_roi_stride, (const int*)offsets, (const int*)list, (const int*)lmeta,
+                       (const float*)wtab, ntiles, nchunks);
     ARFE_CHECK_LAUNCH();
     return ARFE_OK;
 }
