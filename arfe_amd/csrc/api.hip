@@ -15,6 +15,33 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+__global__ __launch_bounds__(256) void zero_buffers_kernel(ZeroList z) {
+    const int b = blockIdx.y;
+    if (b >= z.n) return;
+    uint32_t* p = (uint32_t*)z.p[b];
+    const int64_t n = z.words[b];
+    const int64_t stride = (int64_t)gridDim.x * 256 * 4;
+    const bool aligned = ((uintptr_t)p & 15) == 0;
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+        if (aligned && i + 3 < n) {
+            *reinterpret_cast<uint4*>(p + i) = make_uint4(0u, 0u, 0u, 0u);
+        } else {
+            for (int e = 0; e < 4 && i + e < n; ++e) p[i + e] = 0u;
+        }
+    }
+}
+
+int32_t zero_buffers(const ZeroList& z, hipStream_t stream) {
+    if (z.n == 0) return ARFE_OK;
+    int64_t mx = 0;
+    for (int i = 0; i < z.n; ++i) mx = z.words[i] > mx ? z.words[i] : mx;
+    int gx = (int)cdiv64(mx, 256 * 4 * 4);            // ~4 quads per thread for the largest buffer
+    gx = gx < 1 ? 1 : (gx > 4096 ? 4096 : gx);
+    hipLaunchKernelGGL(zero_buffers_kernel, dim3(gx, z.n), dim3(256), 0, stream, z);
+    ARFE_CHECK_LAUNCH();
+    return ARFE_OK;
+}
+
 bool gemm_use_f32() {
     static int cached = -1;           // process-level switch, read once: ARFE_GEMM_F32=1 -> exact-fp32 MFMA
     if (cached < 0) {

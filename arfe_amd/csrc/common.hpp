@@ -107,6 +107,15 @@ static inline Levels to_levels(const arfe_pyramid_t* p) {
     return l;
 }
 int32_t check_pyramid(const arfe_pyramid_t* p);
+
+// One launch that zero-fills up to 8 buffers of 4-byte words (a hipMemsetAsync per buffer is one ~6 us launch each and
+// the hot path needs up to six in a row).  Entries with a null pointer or zero length are skipped.
+struct ZeroList {
+    void* p[8]; int64_t words[8]; int n;
+    ZeroList() : n(0) {}
+    void add(void* ptr, int64_t nwords) { if (ptr && nwords > 0 && n < 8) { p[n] = ptr; words[n] = nwords; ++n; } }
+};
+int32_t zero_buffers(const ZeroList& z, hipStream_t stream);
 bool gemm_use_f32();
 
 template <int N>

@@ -408,8 +408,13 @@ extern "C" int32_t arfe_linear_bwd(int32_t R, int32_t in_f, int32_t out_f, const
                                    float* db, void* stream) {
     ARFE_CHECK_ARG(R >= 0 && in_f > 0 && out_f > 0, ARFE_ERR_ARG, "linear_bwd: bad shape");
     hipStream_t st = as_stream(stream);
-    if (dw && hipMemsetAsync(dw, 0, sizeof(float) * (size_t)out_f * in_f, st) != hipSuccess) return ARFE_ERR_LAUNCH;
-    if (db && hipMemsetAsync(db, 0, sizeof(float) * (size_t)out_f, st) != hipSuccess) return ARFE_ERR_LAUNCH;
+    {
+        ZeroList z;
+        z.add(dw, (int64_t)out_f * in_f);
+        z.add(db, out_f);
+        int32_t zr = zero_buffers(z, st);
+        if (zr) return zr;
+    }
     if (R == 0) return ARFE_OK;
     ARFE_CHECK_ARG(x && w && dy, ARFE_ERR_ARG, "linear_bwd: null pointer");
     int32_t rc;
@@ -508,15 +513,22 @@ extern "C" int32_t arfe_conv3x3_bwd_weight(int32_t R, int32_t C, const float* x,
                                            void* workspace, void* stream) {
     ARFE_CHECK_ARG(R >= 0 && C > 0 && dw && db, ARFE_ERR_ARG, "conv3x3_bwd_weight: bad arguments");
     hipStream_t st = as_stream(stream);
-    if (hipMemsetAsync(db, 0, sizeof(float) * (size_t)C, st) != hipSuccess) return ARFE_ERR_LAUNCH;
     if (R == 0) {
-        if (hipMemsetAsync(dw, 0, sizeof(float) * (size_t)9 * C * C, st) != hipSuccess) return ARFE_ERR_LAUNCH;
-        return ARFE_OK;
+        ZeroList z;
+        z.add(db, C);
+        z.add(dw, (int64_t)9 * C * C);
+        return zero_buffers(z, st);
     }
     ARFE_CHECK_ARG(x && dy && workspace, ARFE_ERR_ARG, "conv3x3_bwd_weight: null pointer");
     float* dwp = (float*)workspace;
     int total = 9 * C * C;
-    if (hipMemsetAsync(dwp, 0, sizeof(float) * (size_t)total, st) != hipSuccess) return ARFE_ERR_LAUNCH;
+    {
+        ZeroList z;
+        z.add(db, C);
+        z.add(dwp, total);
+        int32_t zr = zero_buffers(z, st);
+        if (zr) return zr;
+    }
     WgradA la{dy, dy_roi_stride, C, R};
     WgradB lb{x, x_roi_stride, C, R};
     const int Kp = R * WG_PAD;
@@ -620,11 +632,16 @@ extern "C" int32_t arfe_nonlocal_bwd(int32_t B, int32_t C, int32_t L, const floa
     hipLaunchKernelGGL(nl_pack_kernel, dim3(cdiv(3 * C * C, 256)), dim3(256), 0, st, w_theta, w_phi, w_g,
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, wcat, (float*)nullptr, C);
     ARFE_CHECK_LAUNCH();
-    if (hipMemsetAsync(dwcat, 0, sizeof(float) * ((size_t)3 * C * C + 3 * C), st) != hipSuccess) return ARFE_ERR_LAUNCH;
-    if (hipMemsetAsync(dtpg, 0, sizeof(float) * (size_t)B * 3 * CL, st) != hipSuccess) return ARFE_ERR_LAUNCH;
-    if (hipMemsetAsync(dw_out, 0, sizeof(float) * (size_t)C * C, st) != hipSuccess) return ARFE_ERR_LAUNCH;
-    if (hipMemsetAsync(db_out, 0, sizeof(float) * (size_t)C, st) != hipSuccess) return ARFE_ERR_LAUNCH;
     int32_t rc;
+    {
+        ZeroList z;
+        z.add(dwcat, (int64_t)3 * C * C + 3 * C);
+        z.add(dtpg, (int64_t)B * 3 * CL);
+        z.add(dw_out, (int64_t)C * C);
+        z.add(db_out, C);
+        rc = zero_buffers(z, st);
+        if (rc) return rc;
+    }
     const int kstepsL = cdiv(L, gemm_bk());
     {   // dw_out[co][ci] = sum_{z,l} dbsf[z][co][l] y[z][ci][l]   (k-batched over images, split-K)
         LoadRowMajorK la{dbsf, 0, CL, L, C, L};

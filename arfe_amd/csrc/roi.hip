@@ -785,9 +785,12 @@ extern "C" int32_t arfe_roialign_bwd(const arfe_pyramid_t* pyr, float* const* df
     RoiWeightHdr* hdr = (RoiWeightHdr*)after;
     float* wtab = (float*)(hdr + nroi_all);
     hipStream_t st = as_stream(stream);
-    if (hipMemsetAsync(counts, 0, sizeof(int) * (size_t)ntiles, st) != hipSuccess) {
-        set_error("roialign_bwd: memset failed");
-        return ARFE_ERR_LAUNCH;
+    {   // one launch: the tile counters and the gradient maps (tiles whose list is cut into slices accumulate atomically)
+        ZeroList z;
+        z.add(counts, ntiles);
+        for (int i = 0; i < L.n; ++i) z.add(L.dfeat[i], (int64_t)L.B * L.C * L.H[i] * L.W[i]);
+        rc = zero_buffers(z, st);
+        if (rc) return rc;
     }
     const int nroi = nsets * R;
     if (nroi > 0) {
@@ -805,11 +808,6 @@ extern "C" int32_t arfe_roialign_bwd(const arfe_pyramid_t* pyr, float* const* df
                            (const int*)offsets, cursors, list, (const RoiWeightHdr*)hdr, lmeta);
         ARFE_CHECK_LAUNCH();
     }
-    for (int i = 0; i < L.n; ++i)      // tiles whose list is cut into slices accumulate atomically
-        if (hipMemsetAsync(L.dfeat[i], 0, sizeof(float) * (size_t)L.B * L.C * L.H[i] * L.W[i], st) != hipSuccess) {
-            set_error("roialign_bwd: memset failed");
-            return ARFE_ERR_LAUNCH;
-        }
     const int nchunks = cdiv(L.C, RB_CC);
     ARFE_CHECK_ARG((int64_t)ntiles * nchunks < (int64_t)1 << 31, ARFE_ERR_ARG, "roialign_bwd: pyramid too large");
     hipLaunchKernelGGL(roialign_bwd_tiles_kernel, dim3(ntiles * nchunks, 1, RB_SEGS), dim3(256), 0, st, L, S, T, pooled,
