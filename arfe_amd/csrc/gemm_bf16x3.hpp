@@ -392,6 +392,173 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_large_kernel(GemmDims d, L
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// 256 x 224 variant of the large tile for outputs whose width is a multiple of 224 but gives the 256-wide tile a
+// badly filled last round: the 3x3 convs at R = 1024 have N = 50 176 = 196 x 256 = 224 x 224, i.e. 196 workgroups on
+// 256 CUs become 224 workgroups of 7/8 the work.  8 waves as 4(M) x 2(N), wave tile 64 x 112 = 4 x 7 blocks of
+// v_mfma_f32_16x16x32_bf16 (one instruction spans the whole 32-wide K-step; 112 accumulator registers).  Full K-steps
+// only (K a multiple of 32), otherwise the same pipeline as above.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int XN_BN = 224;
+constexpr int XN_BUF = 2 * (XL_BM + XN_BN) * XB_LD;                 // bf16 elements per buffer: A_hi A_lo B_hi B_lo
+constexpr int XN_LDS_BYTES = 2 * XN_BUF * 2;                        // 153 600
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <class LA, class LB, class EPI>
+__global__ __launch_bounds__(512, 2) void gemm_bf16x3_n224_kernel(GemmDims d, LA la, LB lb, EPI epi) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short xn_lds[];
+    auto img_a = [&](int buf, int lo) -> unsigned short* { return xn_lds + (size_t)buf * XN_BUF + lo * (XL_BM * XB_LD); };
+    auto img_b = [&](int buf, int lo) -> unsigned short* {
+        return xn_lds + (size_t)buf * XN_BUF + 2 * XL_BM * XB_LD + lo * (XN_BN * XB_LD);
+    };
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int z = blockIdx.z;
+
+    int ntiles = d.tiles_m * d.tiles_n;
+    int bid = blockIdx.x;
+    {
+        int q = ntiles >> 3, r = ntiles & 7, x = bid & 7, j = bid >> 3;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+    }
+    const int tm = bid / d.tiles_n, tn = bid % d.tiles_n;
+    const int m0 = tm * XL_BM, n0 = tn * XN_BN;
+
+    const int ksteps_per_kb = d.K / XB_BK;
+    const int per = (d.ksteps_total + d.splitk - 1) / d.splitk;
+    const int s_begin = blockIdx.y * per;
+    int s_end = s_begin + per;
+    if (s_end > d.ksteps_total) s_end = d.ksteps_total;
+    const bool first_split = (blockIdx.y == 0);
+
+    f32x4 acc[4][7];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 7; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int a_row[2], a_oct[2], b_row[2], b_oct[2];
+    bool b_ok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (LA::kfast) { a_oct[i] = tid & 3; a_row[i] = (tid >> 2) + 128 * i; }
+        else           { a_row[i] = tid & 255; a_oct[i] = (tid >> 8) + 2 * i; }
+        if (LB::kfast) { b_oct[i] = tid & 3; b_row[i] = (tid >> 2) + 128 * i; }
+        else           { b_row[i] = tid & 255; b_oct[i] = (tid >> 8) + 2 * i; }
+        b_ok[i] = b_row[i] < XN_BN;                  // rows 224..255 of the staging grid do not exist in this tile
+        if (!b_ok[i]) b_row[i] = XN_BN - 1;
+    }
+    typename LA::Row arow[2];
+    typename LB::Row brow[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        arow[i] = la.row(z, m0 + a_row[i]);
+        brow[i] = lb.row(z, n0 + b_row[i]);
+    }
+    float ra[2][8], rb[2][8];
+    int f_kb = 0, f_ks = 0;
+    auto fetch_seek = [&](int step) {
+        f_kb = d.kb_inner ? step % d.kb_count : step / ksteps_per_kb;
+        f_ks = d.kb_inner ? step / d.kb_count : step - f_kb * ksteps_per_kb;
+    };
+    auto fetch = [&]() {
+        const int kb = f_kb, k0 = f_ks * XB_BK;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) la.template load8<true>(arow[i], z, kb, k0 + 8 * a_oct[i], ra[i]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) lb.template load8<true>(brow[i], z, kb, k0 + 8 * b_oct[i], rb[i]);
+        const int inner = d.kb_inner;
+        int kb2 = f_kb + inner, ks2 = f_ks + 1 - inner;
+        const bool wrap_kb = kb2 == d.kb_count;
+        ks2 += (inner & (wrap_kb ? 1 : 0));
+        kb2 = wrap_kb ? 0 : kb2;
+        const bool wrap_ks = (inner == 0) & (ks2 == ksteps_per_kb);
+        kb2 += wrap_ks ? 1 : 0;
+        ks2 = wrap_ks ? 0 : ks2;
+        f_kb = kb2; f_ks = ks2;
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            bf16x8 hi, lo;
+            split8(ra[i], hi, lo);
+            *reinterpret_cast<bf16x8*>(img_a(buf, 0) + a_row[i] * XB_LD + 8 * a_oct[i]) = hi;
+            *reinterpret_cast<bf16x8*>(img_a(buf, 1) + a_row[i] * XB_LD + 8 * a_oct[i]) = lo;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            bf16x8 hi, lo;
+            split8(rb[i], hi, lo);
+            if (b_ok[i]) {
+                *reinterpret_cast<bf16x8*>(img_b(buf, 0) + b_row[i] * XB_LD + 8 * b_oct[i]) = hi;
+                *reinterpret_cast<bf16x8*>(img_b(buf, 1) + b_row[i] * XB_LD + 8 * b_oct[i]) = lo;
+            }
+        }
+    };
+    auto mma = [&](int buf) {
+        // operand of v_mfma_f32_16x16x32_bf16: lane -> row l15, k = 8*lq .. 8*lq+7 (one 16-byte read per block and image)
+        bf16x8 ah[4], al[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int off = (wm * 64 + t * 16 + l15) * XB_LD + 8 * lq;
+            ah[t] = *reinterpret_cast<const bf16x8*>(img_a(buf, 0) + off);
+            al[t] = *reinterpret_cast<const bf16x8*>(img_a(buf, 1) + off);
+        }
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const int off = (wn * 112 + j * 16 + l15) * XB_LD + 8 * lq;
+            const bf16x8 bh = *reinterpret_cast<const bf16x8*>(img_b(buf, 0) + off);
+            const bf16x8 bl = *reinterpret_cast<const bf16x8*>(img_b(buf, 1) + off);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh, acc[i][j], 0, 0, 0);
+            }
+        }
+    };
+
+    if (s_begin < s_end) {
+        fetch_seek(s_begin);
+        fetch();
+        stash(0);
+        if (s_begin + 1 < s_end) fetch();
+        __syncthreads();
+        int buf = 0;
+        int s = s_begin;
+        for (; s + 2 < s_end; ++s) {
+            stash(buf ^ 1);
+            fetch();
+            mma(buf);
+            __syncthreads();
+            buf ^= 1;
+        }
+        for (; s < s_end; ++s) {
+            if (s + 1 < s_end) stash(buf ^ 1);
+            mma(buf);
+            __syncthreads();
+            buf ^= 1;
+        }
+    } else if (!first_split) {
+        return;
+    }
+    // D layout: lane -> column l15, rows 4*lq + r
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const int n = n0 + wn * 112 + j * 16 + l15;
+            if (n >= d.N) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * 64 + i * 16 + 4 * lq + r;
+                if (m < d.M) epi(z, m, n, acc[i][j][r], first_split);
+            }
+        }
+}
+
 // precision mode of the dense contractions: bf16x3 by default, exact fp32 MFMA with ARFE_GEMM_F32=1
 bool gemm_use_f32();
 
@@ -436,6 +603,32 @@ static inline int32_t launch_gemm_auto(int M, int N, int K, int kb_count, int ba
             const int k = atoi(plan + 1);
             if (k >= 1 && splitk > 1) { splitk = k < d.ksteps_total ? k : d.ksteps_total; splitk_large = splitk; }
             else if (use_large) splitk_large = splitk;
+        }
+    }
+    if (use_large && N % XN_BN == 0 && d.K % XB_BK == 0) {
+        // 224-wide tiles when they fill the chip's rounds better (cost in units of one 256x256 tile's time)
+        const int64_t t256 = (int64_t)cdiv(M, XL_BM) * cdiv(N, XL_BN) * batch * splitk_large;
+        const int64_t t224 = (int64_t)cdiv(M, XL_BM) * (N / XN_BN) * batch * splitk_large;
+        const double c256 = (double)cdiv64(t256, 256), c224 = (double)cdiv64(t224, 256) * (double)XN_BN / XL_BN;
+        static const char* plan = getenv("ARFE_GEMM_PLAN");
+        const bool veto = plan && plan[0] == 'L';
+        if (c224 < c256 && !veto) {
+            splitk = splitk_large;
+            d.splitk = splitk;
+            d.tiles_m = cdiv(M, XL_BM); d.tiles_n = N / XN_BN;
+            static bool attr224 = false;
+            if (!attr224) {
+                if (hipFuncSetAttribute((const void*)gemm_bf16x3_n224_kernel<LA, LB, EPI>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, XN_LDS_BYTES) != hipSuccess) {
+                    set_error("gemm: cannot reserve %d bytes of LDS", XN_LDS_BYTES);
+                    return ARFE_ERR_LAUNCH;
+                }
+                attr224 = true;
+            }
+            dim3 grid(d.tiles_m * d.tiles_n, splitk, batch);
+            hipLaunchKernelGGL((gemm_bf16x3_n224_kernel<LA, LB, EPI>), grid, dim3(512), XN_LDS_BYTES, stream, d, la, lb, epi);
+            ARFE_CHECK_LAUNCH();
+            return ARFE_OK;
         }
     }
     if (use_large) {

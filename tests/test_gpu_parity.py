@@ -320,6 +320,35 @@ def test_full_size_properties(Fn, O, dev):
     assert out.shape == (0, 256, 7, 7)
 
 
+@pytest.mark.parametrize('R', [1024, 1000])
+def test_conv3x3_bench_size_matches_torch_cpu(Fn, dev, R):
+    """The 3x3 conv GEMMs at the bench size (R=1024: N = 50 176 = 224 x 224 takes the 256x224 tile; R=1000 the 256x256
+    one): forward, data gradient and weight gradient against torch-CPU fp32 conv2d (tolerances of the bf16x3 split)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(5)
+    C = 256
+    x = torch.randn(R, C, 7, 7, generator=g)
+    w = torch.randn(C, C, 3, 3, generator=g) * 0.03
+    b = torch.randn(C, generator=g) * 0.1
+    dy = torch.randn(R, C, 7, 7, generator=g)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y_ref = F.conv2d(xr, wr, br, padding=1)
+    y_ref.backward(dy)
+    xd, wd, bd, dyd = x.to(dev), w.to(dev), b.to(dev), dy.to(dev)
+    pk = Fn.conv3x3_pack_op(wd)
+    y = Fn.conv3x3_fwd_op(xd.data_ptr(), C * 49, R, C, pk, bd, False)
+    assert relerr(y, y_ref.detach()) <= TOL
+    dx = torch.empty_like(xd)
+    Fn.conv3x3_bwd_data_op(R, C, pk, dyd, dx.data_ptr(), C * 49)
+    assert relerr(dx, xr.grad) <= TOL_GRAD
+    import ctypes
+    from arfe_amd import hip
+    ws = torch.empty(int(hip.lib().arfe_conv3x3_workspace_bytes(C)), dtype=torch.uint8, device=dev)
+    dw, db = Fn.conv3x3_bwd_weight_op(xd.data_ptr(), C * 49, R, C, wd, dyd, ws)
+    assert relerr(dw, wr.grad) <= TOL_GRAD
+    assert relerr(db, br.grad) <= TOL_GRAD
+
+
 def test_empty_roi_set_flows_through_extractor_and_head(dev):
     """R = 0 (an image batch without proposals) must give empty outputs and zero gradients, not a crash."""
     import arfe_amd
