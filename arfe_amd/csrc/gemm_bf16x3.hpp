@@ -178,6 +178,171 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmDims d, LA la, 
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// fp32-grade contraction on the bf16 pipe ("bf16x6"): a = a1 + a2 + a3 with three bf16 terms (24 significand bits),
+//   a*b ~= a3*b1 + a1*b3 + a2*b2 + a2*b1 + a1*b2 + a1*b1      (dropped terms <= 2^-24 |a||b|)
+// six v_mfma_f32_32x32x16_bf16 per 32x32x16 block = 6/16 of the exact-fp32 MFMA's cycles at fp32-rounding-level
+// accuracy per product.  Used for the contractions marked `exact` (the NonLocal logits feed exp()); ARFE_GEMM_F32=1 still
+// selects the true fp32 MFMA everywhere.  Same 128x128x32 single-buffer pipeline as gemm_bf16x3_kernel, six LDS images.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void split8x3(const float (&v)[8], bf16x8& t1, bf16x8& t2, bf16x8& t3) {
+    u32x4 h, m, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f32x2 x = {v[2 * j], v[2 * j + 1]};
+        const unsigned hw = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2));
+        const f32x2 hf = {__uint_as_float(hw << 16), __uint_as_float(hw & 0xffff0000u)};
+        const f32x2 r1 = x - hf;
+        const unsigned mw = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2));
+        const f32x2 mf = {__uint_as_float(mw << 16), __uint_as_float(mw & 0xffff0000u)};
+        const f32x2 r2 = r1 - mf;
+        h[j] = hw; m[j] = mw;
+        l[j] = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
+    }
+    t1 = __builtin_bit_cast(bf16x8, h);
+    t2 = __builtin_bit_cast(bf16x8, m);
+    t3 = __builtin_bit_cast(bf16x8, l);
+}
+
+template <class LA, class LB, class EPI>
+__global__ __launch_bounds__(256, 2) void gemm_bf16x6_kernel(GemmDims d, LA la, LB lb, EPI epi) {
+    // [operand image: 0..2 A terms, 3..5 B terms][row][k]
+    __shared__ __attribute__((aligned(16))) unsigned short lds[6][GEMM_BM][XB_LD];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int z = blockIdx.z;
+
+    int ntiles = d.tiles_m * d.tiles_n;
+    int bid = blockIdx.x;
+    {
+        int q = ntiles >> 3, r = ntiles & 7, x = bid & 7, j = bid >> 3;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+    }
+    const int tm = bid / d.tiles_n, tn = bid % d.tiles_n;
+    const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
+
+    const int ksteps_per_kb = (d.K + XB_BK - 1) / XB_BK;
+    const int per = (d.ksteps_total + d.splitk - 1) / d.splitk;
+    const int s_begin = blockIdx.y * per;
+    int s_end = s_begin + per;
+    if (s_end > d.ksteps_total) s_end = d.ksteps_total;
+    const bool first_split = (blockIdx.y == 0);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    int a_row[2], a_oct[2], b_row[2], b_oct[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (LA::kfast) { a_oct[i] = tid & 3; a_row[i] = (tid >> 2) + 64 * i; }
+        else           { a_row[i] = tid & 127; a_oct[i] = (tid >> 7) + 2 * i; }
+        if (LB::kfast) { b_oct[i] = tid & 3; b_row[i] = (tid >> 2) + 64 * i; }
+        else           { b_row[i] = tid & 127; b_oct[i] = (tid >> 7) + 2 * i; }
+    }
+    typename LA::Row arow[2];
+    typename LB::Row brow[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        arow[i] = la.row(z, m0 + a_row[i]);
+        brow[i] = lb.row(z, n0 + b_row[i]);
+    }
+    float ra[2][8], rb[2][8];
+    auto fetch = [&](int step) {
+        const int kb = d.kb_inner ? step % d.kb_count : step / ksteps_per_kb;
+        const int k0 = (d.kb_inner ? step / d.kb_count : step - kb * ksteps_per_kb) * XB_BK;
+        const bool full_k = k0 + XB_BK <= d.K;
+        if (full_k) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) la.template load8<true>(arow[i], z, kb, k0 + 8 * a_oct[i], ra[i]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) lb.template load8<true>(brow[i], z, kb, k0 + 8 * b_oct[i], rb[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) la.template load8<false>(arow[i], z, kb, k0 + 8 * a_oct[i], ra[i]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) lb.template load8<false>(brow[i], z, kb, k0 + 8 * b_oct[i], rb[i]);
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            bf16x8 t1, t2, t3;
+            split8x3(ra[i], t1, t2, t3);
+            *reinterpret_cast<bf16x8*>(&lds[0][a_row[i]][8 * a_oct[i]]) = t1;
+            *reinterpret_cast<bf16x8*>(&lds[1][a_row[i]][8 * a_oct[i]]) = t2;
+            *reinterpret_cast<bf16x8*>(&lds[2][a_row[i]][8 * a_oct[i]]) = t3;
+            split8x3(rb[i], t1, t2, t3);
+            *reinterpret_cast<bf16x8*>(&lds[3][b_row[i]][8 * b_oct[i]]) = t1;
+            *reinterpret_cast<bf16x8*>(&lds[4][b_row[i]][8 * b_oct[i]]) = t2;
+            *reinterpret_cast<bf16x8*>(&lds[5][b_row[i]][8 * b_oct[i]]) = t3;
+        }
+    };
+
+    if (s_begin < s_end) {
+        fetch(s_begin);
+        stash();
+        __syncthreads();
+        const int kh = lane >> 5, l31 = lane & 31;
+        for (int s = s_begin; s < s_end; ++s) {
+            const bool more = (s + 1 < s_end);
+            if (more) fetch(s + 1);
+#pragma unroll
+            for (int kk = 0; kk < XB_BK; kk += 16) {
+                bf16x8 a1[2], a2[2], a3[2], b1[2], b2[2], b3[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int ar = wm * 64 + t * 32 + l31, br = wn * 64 + t * 32 + l31;
+                    a1[t] = *reinterpret_cast<const bf16x8*>(&lds[0][ar][kk + 8 * kh]);
+                    a2[t] = *reinterpret_cast<const bf16x8*>(&lds[1][ar][kk + 8 * kh]);
+                    a3[t] = *reinterpret_cast<const bf16x8*>(&lds[2][ar][kk + 8 * kh]);
+                    b1[t] = *reinterpret_cast<const bf16x8*>(&lds[3][br][kk + 8 * kh]);
+                    b2[t] = *reinterpret_cast<const bf16x8*>(&lds[4][br][kk + 8 * kh]);
+                    b3[t] = *reinterpret_cast<const bf16x8*>(&lds[5][br][kk + 8 * kh]);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {       // smallest terms first
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[i], b1[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b3[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[i], b2[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[i], b1[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b2[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b1[j], acc[i][j], 0, 0, 0);
+                    }
+            }
+            __syncthreads();
+            if (more) {
+                stash();
+                __syncthreads();
+            }
+        }
+    } else if (!first_split) {
+        return;
+    }
+
+    const int h = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + l31;
+            if (n >= d.N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m < d.M) epi(z, m, n, acc[i][j][r], first_split);
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Large-tile variant for the big contractions (3x3 convs, FC1, theta^T phi): 256x256x32 tile, 512 threads =
 // 8 waves as 2(M) x 4(N), wave tile 128x64 = 4x2 MFMA blocks (128 accumulator registers).  Against the 128x128
 // kernel every staged operand element feeds twice the MFMAs (LDS write traffic per flop halves; ds_write_b128
@@ -585,8 +750,22 @@ static inline bool plan_large_tile(int M, int N, int batch, int ksteps, int* spl
 template <class LA, class LB, class EPI>
 static inline int32_t launch_gemm_auto(int M, int N, int K, int kb_count, int batch, int splitk, LA la, LB lb, EPI epi,
                                        hipStream_t stream, bool exact = false, bool kb_inner = false) {
-    if (exact || gemm_use_f32()) return launch_gemm(M, N, K, kb_count, batch, splitk, la, lb, epi, stream, kb_inner);
+    if (gemm_use_f32()) return launch_gemm(M, N, K, kb_count, batch, splitk, la, lb, epi, stream, kb_inner);
     if (M <= 0 || N <= 0 || batch <= 0) return ARFE_OK;
+    if (exact) {        // fp32-grade products from six bf16 MFMAs (see gemm_bf16x6_kernel)
+        GemmDims d6;
+        d6.M = M; d6.N = N; d6.K = K; d6.kb_count = kb_count < 1 ? 1 : kb_count;
+        d6.kb_inner = kb_inner ? 1 : 0;
+        d6.ksteps_total = d6.kb_count * cdiv(K, XB_BK);
+        if (splitk < 1) splitk = 1;
+        if (splitk > d6.ksteps_total && d6.ksteps_total > 0) splitk = d6.ksteps_total;
+        d6.splitk = splitk;
+        d6.tiles_m = cdiv(M, GEMM_BM); d6.tiles_n = cdiv(N, GEMM_BN);
+        dim3 grid6(d6.tiles_m * d6.tiles_n, splitk, batch);
+        hipLaunchKernelGGL((gemm_bf16x6_kernel<LA, LB, EPI>), grid6, dim3(256), 0, stream, d6, la, lb, epi);
+        ARFE_CHECK_LAUNCH();
+        return ARFE_OK;
+    }
     GemmDims d;
     d.M = M; d.N = N; d.K = K; d.kb_count = kb_count < 1 ? 1 : kb_count;
     d.kb_inner = kb_inner ? 1 : 0;
