@@ -248,14 +248,23 @@ static inline int32_t launch_gemm(int M, int N, int K, int kb_count, int batch, 
 }
 
 // how many K-slices to cut so that about one wave of workgroups per CU pair is in flight (256 CUs, 2 WG/CU)
+// K-slices for the 128x128 kernels, from a three-term cost model fitted to tools/gemm_sweep.py on MI355X (us):
+//   rounds(tiles * s over 2 workgroups per CU) * (K-steps per slice * 1.8 + 8 fixed)  +  atomic bytes / 1.3 TB/s
+// Small outputs (cls / reg / bias-sized) take many thin slices, large ones few (their atomic traffic dominates).
 static inline int pick_splitk(int M, int N, int batch, int ksteps) {
-    int tiles = cdiv(M, GEMM_BM) * cdiv(N, GEMM_BN) * batch;
-    if (tiles >= 384) return 1;
-    int s = 512 / (tiles > 0 ? tiles : 1);
-    if (s < 1) s = 1;
-    int max_s = ksteps / 8;          // keep at least 8 K-steps per slice
-    if (max_s < 1) max_s = 1;
-    return s < max_s ? s : max_s;
+    const int64_t tiles = (int64_t)cdiv(M, GEMM_BM) * cdiv(N, GEMM_BN) * batch;
+    if (tiles >= 384 || ksteps < 4) return 1;
+    const double out_bytes = 4.0 * (double)M * (double)N * (double)batch;
+    double best = 1e30;
+    int best_s = 1;
+    static const int cand[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128};
+    for (int s : cand) {
+        if (s > 1 && s * 2 > ksteps) break;                 // at least 2 K-steps per slice
+        const double rounds = (double)cdiv64(tiles * s, 512);
+        const double t = rounds * ((double)cdiv(ksteps, s) * 1.8 + 8.0) + (s > 1 ? out_bytes * s / 1.3e6 : 0.0);
+        if (t < best) { best = t; best_s = s; }
+    }
+    return best_s;
 }
 
 }  // namespace arfe
