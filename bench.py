@@ -202,11 +202,12 @@ def main():
                        "per_gpu_batch": B, "global_batch": world * B, "rois_per_gpu": R, "channels": 256,
                        "pyramid": "200x336,100x168,50x84,25x42,13x21", "parallelism": f"image-dp{world}"},
             "roofline": {"bound": "mfma",
-                         "kernel": ("gemm_f32_kernel" if f32_mode else "gemm_bf16x3_large_kernel") +
+                         "kernel": ("gemm_f32_kernel" if f32_mode else
+                                    "gemm_bf16x3_n224_kernel (256x224 tile) / gemm_bf16x3_large_kernel (256x256)") +
                                    "<LoadRowMajorK,ConvGatherB,EpiConv> (3x3 conv 256->256 on [R,256,7,7], fwd + data-grad)",
                          "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(ach / peak, 4),
-                         "traffic": None if f32_mode else pmc_traffic(("gemm_bf16x3_large_kernel", "ConvGatherB")),
+                         "traffic": None if f32_mode else pmc_traffic(("gemm_bf16x3_", "ConvGatherB")),
                          "traffic_unit": "bytes/launch (PMC, profiles/r01_pmc_hbm_traffic.json)",
                          "algorithmic_bytes_per_launch": int(2 * R * 256 * 49 * 4 + 9 * 256 * 256 * 4),
                          "mfma_flop_per_algorithmic_flop": 1 if f32_mode else 3,
