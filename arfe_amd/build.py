@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libarfe_hip.so")
-SOURCES = ["api.hip", "fpn.hip", "roi.hip", "gemm_ops.hip"]
+SOURCES = ["api.hip", "fpn.hip", "roi.hip", "gemm_ops.hip", "fpn_base.hip"]
 HEADERS = ["common.hpp", "gemm_f32.hpp", "gemm_bf16x3.hpp", os.path.join("..", "..", "include", "arfe_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc",

@@ -116,6 +116,8 @@ struct ZeroList {
     void add(void* ptr, int64_t nwords) { if (ptr && nwords > 0 && n < 8) { p[n] = ptr; words[n] = nwords; ++n; } }
 };
 int32_t zero_buffers(const ZeroList& z, hipStream_t stream);
+// dwp[tap][co][ci] -> dw[co][ci][tap] (gemm_ops.hip)
+int32_t conv3x3_unpermute_dw(int C, const float* dwp, float* dw, hipStream_t stream);
 bool gemm_use_f32();
 
 template <int N>

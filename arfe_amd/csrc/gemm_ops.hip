@@ -352,6 +352,13 @@ static inline int32_t gemm_autosplit(int M, int N, int K, int kb, int batch, LA 
     return launch_gemm_auto(M, N, K, kb, batch, splitk, la, lb, e, st);
 }
 
+int32_t conv3x3_unpermute_dw(int C, const float* dwp, float* dw, hipStream_t stream) {
+    const int total = 9 * C * C;
+    hipLaunchKernelGGL(conv_dw_unpermute_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, dwp, dw, C);
+    ARFE_CHECK_LAUNCH();
+    return ARFE_OK;
+}
+
 // 8*49 zero floats, allocated once per process (the padding taps of ConvGatherB point here)
 static const float* conv_zeros() {
     static const float* z = []() -> const float* {

@@ -487,3 +487,132 @@ class RFFHeadFunction(torch.autograd.Function):
 
 def rff_head(x, w_wh, b_wh, w_hh, b_hh, w_f, b_f, w1, b1, w2, b2, wc, bc, wr, br):
     return RFFHeadFunction.apply(x, w_wh, b_wh, w_hh, b_hh, w_f, b_f, w1, b1, w2, b2, wc, bc, wr, br)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# base FPN (reference necks/fpn.py): per-op autograd nodes, composed by necks.FPN
+# ---------------------------------------------------------------------------------------------------------
+
+class Conv1x1Function(torch.autograd.Function):
+    """ConvModule(cin, cout, 1, act_cfg=None): y = W x + b on [B, Cin, H, W] (fpn.py:117-124)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x, w, b = x.contiguous(), w.contiguous(), b.contiguous()
+        hip.require_f32_cuda(x, w, b)
+        B, cin, H, W = x.shape
+        cout = w.shape[0]
+        y = torch.empty(B, cout, H, W, device=x.device)
+        check(hip.lib().arfe_conv1x1_fwd(B, cin, cout, H * W, ptr(x), ptr(w), ptr(b), ptr(y), stream()), "arfe_conv1x1_fwd")
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        B, cin, H, W = x.shape
+        cout = w.shape[0]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            check(hip.lib().arfe_conv1x1_bwd_data(B, cin, cout, H * W, ptr(w), ptr(dy), ptr(dx), stream()),
+                  "arfe_conv1x1_bwd_data")
+        dw, db = torch.empty_like(w), torch.empty(cout, device=x.device)
+        check(hip.lib().arfe_conv1x1_bwd_weight(B, cin, cout, H * W, ptr(x), ptr(dy), ptr(dw), ptr(db), stream()),
+              "arfe_conv1x1_bwd_weight")
+        return dx, dw, db
+
+
+class ConvMap3x3Function(torch.autograd.Function):
+    """ConvModule(c, c, 3, padding=1, act_cfg=None) on whole feature maps (fpn.py:125-133)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x, w, b = x.contiguous(), w.contiguous(), b.contiguous()
+        hip.require_f32_cuda(x, w, b)
+        B, C, H, W = x.shape
+        if w.shape != (C, C, 3, 3):
+            raise hip.ArfeHipError(f"conv3x3 on maps needs square C -> C weights, got {tuple(w.shape)} for C={C}")
+        pk = conv3x3_pack_op(w)
+        y = torch.empty_like(x)
+        check(hip.lib().arfe_convmap3x3_fwd(B, C, H, W, ptr(x), ptr(pk), ptr(b), ptr(y), stream()), "arfe_convmap3x3_fwd")
+        ctx.save_for_backward(x, w, pk)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, pk = ctx.saved_tensors
+        dy = dy.contiguous()
+        B, C, H, W = x.shape
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            check(hip.lib().arfe_convmap3x3_bwd_data(B, C, H, W, ptr(pk), ptr(dy), ptr(dx), stream()),
+                  "arfe_convmap3x3_bwd_data")
+        dw, db = torch.empty_like(w), torch.empty(C, device=x.device)
+        ws = _ws(hip.lib().arfe_conv3x3_workspace_bytes(C), x.device)
+        check(hip.lib().arfe_convmap3x3_bwd_weight(B, C, H, W, ptr(x), ptr(dy), ptr(dw), ptr(db), ptr(ws), stream()),
+              "arfe_convmap3x3_bwd_weight")
+        return dx, dw, db
+
+
+class NearestAddFunction(torch.autograd.Function):
+    """lat + F.interpolate(top, size=lat.shape[2:], mode='nearest') (fpn.py:180-188)."""
+
+    @staticmethod
+    def forward(ctx, lat, top):
+        lat, top = lat.contiguous(), top.contiguous()
+        hip.require_f32_cuda(lat, top)
+        B, C, H, W = lat.shape
+        h, w = top.shape[2:]
+        out = lat.clone()
+        check(hip.lib().arfe_nearest_add_fwd(B, C, h, w, ptr(top), H, W, ptr(out), stream()), "arfe_nearest_add_fwd")
+        ctx.shapes = (B, C, h, w, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, C, h, w, H, W = ctx.shapes
+        g = g.contiguous()
+        dtop = torch.zeros(B, C, h, w, device=g.device)
+        check(hip.lib().arfe_nearest_add_bwd(B, C, h, w, ptr(dtop), H, W, ptr(g), stream()), "arfe_nearest_add_bwd")
+        return g, dtop
+
+
+class Subsample2Function(torch.autograd.Function):
+    """F.max_pool2d(x, 1, stride=2) (fpn.py:199-201)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        hip.require_f32_cuda(x)
+        B, C, H, W = x.shape
+        out = torch.empty(B, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1, device=x.device)
+        check(hip.lib().arfe_subsample2(B, C, H, W, ptr(x), ptr(out), 0, stream()), "arfe_subsample2")
+        ctx.shape = (B, C, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, C, H, W = ctx.shape
+        g = g.contiguous()
+        dx = torch.empty(B, C, H, W, device=g.device)
+        check(hip.lib().arfe_subsample2(B, C, H, W, ptr(g), ptr(dx), 1, stream()), "arfe_subsample2")
+        return dx
+
+
+def conv1x1(x, w, b):
+    return Conv1x1Function.apply(x, w, b)
+
+
+def convmap3x3(x, w, b):
+    return ConvMap3x3Function.apply(x, w, b)
+
+
+def nearest_add(lat, top):
+    return NearestAddFunction.apply(lat, top)
+
+
+def subsample2(x):
+    return Subsample2Function.apply(x)

@@ -65,6 +65,15 @@ SIGNATURES = {
     "arfe_rff_fuse_bwd": (_i32, [_i32, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "arfe_linear_fwd": (_i32, [_i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _vp]),
     "arfe_linear_bwd": (_i32, [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
+    "arfe_conv1x1_fwd": (_i32, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "arfe_conv1x1_bwd_data": (_i32, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "arfe_conv1x1_bwd_weight": (_i32, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "arfe_convmap3x3_fwd": (_i32, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "arfe_convmap3x3_bwd_data": (_i32, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "arfe_convmap3x3_bwd_weight": (_i32, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "arfe_nearest_add_fwd": (_i32, [_i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp]),
+    "arfe_nearest_add_bwd": (_i32, [_i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp]),
+    "arfe_subsample2": (_i32, [_i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
 }
 
 _lib = None

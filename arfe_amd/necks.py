@@ -40,3 +40,62 @@ class WFPNDualSpatial(nn.Module):
         b2 = [m.conv.bias for m in self.reduce_convs2]
         return tuple(Fn.arfpn(list(inputs), w1, b1, w2, b2, *self.refine.hip_params(),
                               refine_level=self.refine_level))
+
+
+@NECKS.register_module()
+class FPN(nn.Module):
+    """Base FPN with the constructor, registry name and state_dict keys of the reference (mmdet/models/necks/fpn.py:10-164);
+    SURVEY 8(f) row 2.  The configuration of the AR configs is implemented: no norm / activation in the ConvModules,
+    nearest top-down upsampling, extra levels by `max_pool2d(1, stride=2)` (add_extra_convs=False)."""
+
+    def __init__(self, in_channels, out_channels, num_outs, start_level=0, end_level=-1, add_extra_convs=False,
+                 extra_convs_on_inputs=True, relu_before_extra_convs=False, no_norm_on_lateral=False, conv_cfg=None,
+                 norm_cfg=None, act_cfg=None, upsample_cfg=dict(mode='nearest')):
+        super().__init__()
+        assert isinstance(in_channels, list)
+        if add_extra_convs:
+            raise NotImplementedError("FPN extra levels by stride-2 convs (RetinaNet) are outside the AR configs")
+        if act_cfg is not None or norm_cfg is not None or conv_cfg is not None:
+            raise NotImplementedError("FPN ConvModules of the AR configs have no norm / activation")
+        if dict(upsample_cfg) != dict(mode='nearest'):
+            raise NotImplementedError(f"only upsample_cfg=dict(mode='nearest') has a kernel (got {upsample_cfg})")
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.num_ins = len(in_channels)
+        self.num_outs = num_outs
+        self.relu_before_extra_convs = relu_before_extra_convs
+        self.no_norm_on_lateral = no_norm_on_lateral
+        self.fp16_enabled = False
+        self.upsample_cfg = dict(upsample_cfg)
+        if end_level == -1:
+            self.backbone_end_level = self.num_ins
+            assert num_outs >= self.num_ins - start_level
+        else:
+            self.backbone_end_level = end_level
+            assert end_level <= len(in_channels)
+            assert num_outs == end_level - start_level
+        self.start_level = start_level
+        self.end_level = end_level
+        self.add_extra_convs = add_extra_convs
+        self.lateral_convs = nn.ModuleList()
+        self.fpn_convs = nn.ModuleList()
+        for i in range(self.start_level, self.backbone_end_level):
+            self.lateral_convs.append(ConvModule(in_channels[i], out_channels, 1, act_cfg=None, inplace=False))
+            self.fpn_convs.append(ConvModule(out_channels, out_channels, 3, padding=1, act_cfg=None, inplace=False))
+
+    def init_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                xavier_init(m, distribution='uniform')
+
+    def forward(self, inputs):
+        assert len(inputs) == len(self.in_channels)
+        laterals = [Fn.conv1x1(inputs[i + self.start_level], m.conv.weight, m.conv.bias)
+                    for i, m in enumerate(self.lateral_convs)]
+        used = len(laterals)
+        for i in range(used - 1, 0, -1):
+            laterals[i - 1] = Fn.nearest_add(laterals[i - 1], laterals[i])
+        outs = [Fn.convmap3x3(laterals[i], self.fpn_convs[i].conv.weight, self.fpn_convs[i].conv.bias) for i in range(used)]
+        for _ in range(self.num_outs - used):
+            outs.append(Fn.subsample2(outs[-1]))
+        return tuple(outs)

@@ -193,6 +193,33 @@ int32_t arfe_linear_bwd(int32_t R, int32_t in_f, int32_t out_f, const float* x, 
                         const float* dy, float* dx, int32_t accumulate_dx, int32_t mask_dx_by_x, float* dw,
                         float* db, void* stream);
 
+/* ---- base FPN: mmdet/models/necks/fpn.py:166-201 ----------------------------------------------
+ * The lateral 1x1 convs (fpn.py:117-124,170-173), the top-down `laterals[i-1] += F.interpolate(laterals[i], size=...)`
+ * (fpn.py:180-188, mode nearest), the 3x3 output convs (fpn.py:125-133,192-194) and the stride-2 extra levels
+ * `F.max_pool2d(outs[-1], 1, stride=2)` (fpn.py:199-201).  All tensors contiguous NCHW fp32 device memory. */
+/* y[B,Cout,HW] = W[Cout,Cin] x[B,Cin,HW] + b (b may be NULL) */
+int32_t arfe_conv1x1_fwd(int32_t B, int32_t Cin, int32_t Cout, int32_t HW, const float* x, const float* w,
+                         const float* b, float* y, void* stream);
+int32_t arfe_conv1x1_bwd_data(int32_t B, int32_t Cin, int32_t Cout, int32_t HW, const float* w, const float* dy,
+                              float* dx, void* stream);
+int32_t arfe_conv1x1_bwd_weight(int32_t B, int32_t Cin, int32_t Cout, int32_t HW, const float* x, const float* dy,
+                                float* dw, float* db, void* stream);
+/* 3x3, padding 1, C -> C on whole maps; `packed` from arfe_conv3x3_pack_weights; workspace arfe_conv3x3_workspace_bytes(C) */
+int32_t arfe_convmap3x3_fwd(int32_t B, int32_t C, int32_t H, int32_t W, const float* x, const void* packed,
+                            const float* b, float* y, void* stream);
+int32_t arfe_convmap3x3_bwd_data(int32_t B, int32_t C, int32_t H, int32_t W, const void* packed, const float* dy,
+                                 float* dx, void* stream);
+int32_t arfe_convmap3x3_bwd_weight(int32_t B, int32_t C, int32_t H, int32_t W, const float* x, const float* dy,
+                                   float* dw, float* db, void* workspace, void* stream);
+/* lat[B,C,H,W] += nearest(top[B,C,h,w] -> H x W); backward: dtop += nearest^T(dlat) */
+int32_t arfe_nearest_add_fwd(int32_t B, int32_t C, int32_t h, int32_t w, const float* top, int32_t H, int32_t W,
+                             float* lat, void* stream);
+int32_t arfe_nearest_add_bwd(int32_t B, int32_t C, int32_t h, int32_t w, float* dtop, int32_t H, int32_t W,
+                             const float* dlat, void* stream);
+/* backward == 0: out[B,C,(H-1)/2+1,(W-1)/2+1] = in[B,C,H,W][::2, ::2]; backward != 0: out[B,C,H,W] = scatter of in */
+int32_t arfe_subsample2(int32_t B, int32_t C, int32_t H, int32_t W, const float* in, float* out, int32_t backward,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

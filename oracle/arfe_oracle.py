@@ -130,6 +130,37 @@ def arfpn_forward(xs, p, refine_level=2, explicit=False, return_parts=False):
 
 
 # ----------------------------------------------------------------------------------------
+# base FPN -- restated from necks/fpn.py
+# ----------------------------------------------------------------------------------------
+
+def fpn_params(in_channels, out_channels=256, seed=0):
+    """state_dict-shaped params of FPN(in_channels, out_channels, num_outs) with add_extra_convs=False:
+    lateral_convs.i.conv (1x1) and fpn_convs.i.conv (3x3, padding 1), xavier-uniform, zero bias (fpn.py:117-138,161-164)."""
+    gen = torch.Generator().manual_seed(seed)
+    p = {}
+    for i, cin in enumerate(in_channels):
+        p[f'lateral_convs.{i}.conv.weight'] = _xavier_uniform((out_channels, cin, 1, 1), gen)
+        p[f'lateral_convs.{i}.conv.bias'] = torch.zeros(out_channels)
+        p[f'fpn_convs.{i}.conv.weight'] = _xavier_uniform((out_channels, out_channels, 3, 3), gen)
+        p[f'fpn_convs.{i}.conv.bias'] = torch.zeros(out_channels)
+    return p
+
+
+def fpn_forward(inputs, p, num_outs):
+    """FPN.forward with start_level=0, end_level=-1, add_extra_convs=False, act/norm None (fpn.py:166-201):
+    laterals = conv1x1(x_i)+b; top-down: lat[i-1] += nearest(lat[i], size of lat[i-1]); outs = conv3x3(lat_i)+b;
+    extra levels = max_pool2d(outs[-1], 1, stride=2)."""
+    n = len(inputs)
+    lat = [F.conv2d(inputs[i], p[f'lateral_convs.{i}.conv.weight'], p[f'lateral_convs.{i}.conv.bias']) for i in range(n)]
+    for i in range(n - 1, 0, -1):
+        lat[i - 1] = lat[i - 1] + F.interpolate(lat[i], size=lat[i - 1].shape[2:], mode='nearest')
+    outs = [F.conv2d(lat[i], p[f'fpn_convs.{i}.conv.weight'], p[f'fpn_convs.{i}.conv.bias'], padding=1) for i in range(n)]
+    for _ in range(num_outs - n):
+        outs.append(F.max_pool2d(outs[-1], 1, stride=2))
+    return tuple(outs)
+
+
+# ----------------------------------------------------------------------------------------
 # AR-RFF
 # ----------------------------------------------------------------------------------------
 

@@ -235,6 +235,32 @@ def e2e_case(ns):
     print('e2e ok')
 
 
+def fpn_case(ns, name, in_channels, out_channels, sizes, batch, num_outs, seed):
+    """Base FPN (necks/fpn.py) forward + backward on seeded inputs; sizes may be ragged (odd halves)."""
+    gen = torch.Generator().manual_seed(seed)
+    torch.manual_seed(seed)
+    neck = ns.FPN(list(in_channels), out_channels, num_outs)
+    neck.init_weights()
+    randomise(neck, gen)
+    xs = [torch.randn(batch, c, h, w, generator=gen, requires_grad=True) for c, (h, w) in zip(in_channels, sizes)]
+    outs = neck(xs)
+    cots = [torch.randn(o.shape, generator=gen) for o in outs]
+    loss = sum((o * c).sum() for o, c in zip(outs, cots))
+    loss.backward()
+    d = {'num_outs': num_outs}
+    for i in range(len(xs)):
+        d[f'x{i}'] = xs[i]
+        d[f'dx{i}'] = xs[i].grad
+    for i in range(len(outs)):
+        d[f'cot{i}'] = cots[i]
+        d[f'out{i}'] = outs[i]
+    for n, p in neck.named_parameters():
+        d['p.' + n] = p
+        d['dp.' + n] = p.grad
+    np.savez_compressed(os.path.join(OUT, name), **npd(d))
+    print('wrote', name)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ns = load_reference()
@@ -252,7 +278,17 @@ def main():
     head_case(ns, 'rff_head_r8.npz', 16, 32, 8, seed=6)
     head_case(ns, 'rff_head_r40.npz', 8, 24, 40, seed=7)
     e2e_case(ns)
+    fpn_cases(ns)
+
+
+def fpn_cases(ns):
+    fpn_case(ns, 'fpn_tiny.npz', (4, 6, 8, 10), 8, ((16, 24), (8, 12), (4, 6), (2, 3)), 2, 5, seed=11)
+    fpn_case(ns, 'fpn_ragged.npz', (8, 16, 24, 32), 16, ((41, 67), (21, 34), (11, 17), (6, 9)), 1, 5, seed=12)
 
 
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'fpn':     # only the base-FPN fixtures (keeps the others byte-identical)
+        os.makedirs(OUT, exist_ok=True)
+        fpn_cases(load_reference())
+    else:
+        main()

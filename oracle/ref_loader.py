@@ -161,6 +161,7 @@ def load_reference():
     nl = _load('mmdet.ops.non_local', 'mmdet/ops/non_local.py')
     sys.modules['mmdet.ops'].NonLocal2D = nl.NonLocal2D
     neck = _load('mmdet.models.necks.wfpn_dual_spatial', 'mmdet/models/necks/wfpn_dual_spatial.py')
+    fpn = _load('mmdet.models.necks.fpn', 'mmdet/models/necks/fpn.py')
     add = _load('mmdet.models.utils.additional', 'mmdet/models/utils/additional.py')
     sys.modules['mmdet'].ops = sys.modules['mmdet.ops']
     bh = _load('mmdet.models.roi_heads.bbox_heads.bbox_head',
@@ -184,6 +185,7 @@ def load_reference():
         roi_align_ext=ext_mod,
         NonLocal2D=nl.NonLocal2D,
         WFPNDualSpatial=neck.WFPNDualSpatial,
+        FPN=fpn.FPN,
         get_adaptive_scale_rois=add.get_adaptive_scale_rois,
         BBoxHead=bh.BBoxHead,
         MultiBBoxHead=mh.MultiBBoxHead,
