@@ -95,7 +95,7 @@ struct WgradMapB {
 
 // lat[b][c][Y][X] += top[b][c][nearest(Y), nearest(X)]  (F.interpolate(size=...), legacy nearest index)
 __global__ void nearest_add_fwd_kernel(int64_t total, int h, int w, int H, int W, const float* __restrict__ top,
-                                       float* __restrict__ lat) {
+                                       const float* __restrict__ lat, float* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int X = (int)(i % W);
@@ -103,7 +103,7 @@ __global__ void nearest_add_fwd_kernel(int64_t total, int h, int w, int H, int W
     const int Y = (int)(r % H);
     const int64_t bc = r / H;
     const float ys = nearest_scale(h, H), xs = nearest_scale(w, W);
-    lat[i] += top[(bc * h + nearest_src(Y, h, ys)) * w + nearest_src(X, w, xs)];
+    out[i] = lat[i] + top[(bc * h + nearest_src(Y, h, ys)) * w + nearest_src(X, w, xs)];
 }
 // dtop[b][c][y][x] += sum of dlat over the destination pixels that read (y, x)
 __global__ void nearest_add_bwd_kernel(int64_t total, int h, int w, int H, int W, const float* __restrict__ dlat,
@@ -143,19 +143,25 @@ __global__ void subsample2_kernel(int64_t total, int h, int w, int H, int W, con
 }
 
 __global__ void rowsum_kb_kernel(const float* __restrict__ x, float* __restrict__ out, int batch, int64_t batch_stride,
-                                 int inner) {
-    // out[row] = sum_{b, i} x[b*batch_stride + row*inner + i]; one workgroup per row
-    const int row = blockIdx.x;
+                                 int inner, int chunk) {
+    // out[row] += sum_{b, i in chunk} x[b*batch_stride + row*inner + i]; grid = (rows, chunks of the row, images)
+    const int row = blockIdx.x, b = blockIdx.z;
+    const int i0 = blockIdx.y * chunk, i1 = i0 + chunk < inner ? i0 + chunk : inner;
+    const float* p = x + b * batch_stride + (int64_t)row * inner;
     float s = 0.f;
-    for (int b = 0; b < batch; ++b) {
-        const float* p = x + b * batch_stride + (int64_t)row * inner;
-        for (int i = threadIdx.x; i < inner; i += blockDim.x) s += p[i];
-    }
+    for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) s += p[i];
     s = wave_sum(s);
     __shared__ float part[4];
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) out[row] = (part[0] + part[1]) + (part[2] + part[3]);
+    if (threadIdx.x == 0) unsafeAtomicAdd(out + row, (part[0] + part[1]) + (part[2] + part[3]));
+    (void)batch;
+}
+static inline void launch_rowsum(const float* x, float* out, int rows, int batch, int64_t batch_stride, int inner,
+                                 hipStream_t st) {
+    const int chunk = 4096;
+    hipLaunchKernelGGL(rowsum_kb_kernel, dim3(rows, cdiv(inner, chunk), batch), dim3(256), 0, st, x, out, batch, batch_stride,
+                       inner, chunk);
 }
 
 }  // namespace arfe
@@ -207,7 +213,7 @@ extern "C" int32_t arfe_conv1x1_bwd_weight(int32_t B, int32_t Cin, int32_t Cout,
     const int ksteps = B * cdiv(HW, gemm_bk());
     int32_t rc = launch_gemm_auto(Cout, Cin, HW, B, 1, pick_splitk(Cout, Cin, 1, ksteps), la, lb, e, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(rowsum_kb_kernel, dim3(Cout), dim3(256), 0, st, dy, db, B, (int64_t)Cout * HW, HW);
+    launch_rowsum(dy, db, Cout, B, (int64_t)Cout * HW, HW, st);
     ARFE_CHECK_LAUNCH();
     return ARFE_OK;
 }
@@ -256,6 +262,7 @@ extern "C" int32_t arfe_convmap3x3_bwd_weight(int32_t B, int32_t C, int32_t H, i
     {
         ZeroList z;
         z.add(dwp, (int64_t)9 * C * C);
+        z.add(db, C);
         int32_t rc = zero_buffers(z, st);
         if (rc) return rc;
     }
@@ -269,19 +276,19 @@ extern "C" int32_t arfe_convmap3x3_bwd_weight(int32_t B, int32_t C, int32_t H, i
     if (rc) return rc;
     rc = conv3x3_unpermute_dw(C, dwp, dw, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(rowsum_kb_kernel, dim3(C), dim3(256), 0, st, dy, db, B, (int64_t)C * HW, HW);
+    launch_rowsum(dy, db, C, B, (int64_t)C * HW, HW, st);
     ARFE_CHECK_LAUNCH();
     return ARFE_OK;
 }
 
 extern "C" int32_t arfe_nearest_add_fwd(int32_t B, int32_t C, int32_t h, int32_t w, const float* top, int32_t H, int32_t W,
-                                        float* lat, void* stream) {
+                                        const float* lat, float* out, void* stream) {
     ARFE_CHECK_ARG(B >= 0 && C > 0 && h > 0 && w > 0 && H > 0 && W > 0, ARFE_ERR_ARG, "nearest_add_fwd: bad shape");
     if (B == 0) return ARFE_OK;
-    ARFE_CHECK_ARG(top && lat, ARFE_ERR_ARG, "nearest_add_fwd: null pointer");
+    ARFE_CHECK_ARG(top && lat && out, ARFE_ERR_ARG, "nearest_add_fwd: null pointer");
     const int64_t total = (int64_t)B * C * H * W;
     hipLaunchKernelGGL(nearest_add_fwd_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, as_stream(stream), total, h, w,
-                       H, W, top, lat);
+                       H, W, top, lat, out);
     ARFE_CHECK_LAUNCH();
     return ARFE_OK;
 }

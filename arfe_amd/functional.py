@@ -566,8 +566,8 @@ class NearestAddFunction(torch.autograd.Function):
         hip.require_f32_cuda(lat, top)
         B, C, H, W = lat.shape
         h, w = top.shape[2:]
-        out = lat.clone()
-        check(hip.lib().arfe_nearest_add_fwd(B, C, h, w, ptr(top), H, W, ptr(out), stream()), "arfe_nearest_add_fwd")
+        out = torch.empty_like(lat)
+        check(hip.lib().arfe_nearest_add_fwd(B, C, h, w, ptr(top), H, W, ptr(lat), ptr(out), stream()), "arfe_nearest_add_fwd")
         ctx.shapes = (B, C, h, w, H, W)
         return out
 

@@ -71,7 +71,7 @@ SIGNATURES = {
     "arfe_convmap3x3_fwd": (_i32, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "arfe_convmap3x3_bwd_data": (_i32, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "arfe_convmap3x3_bwd_weight": (_i32, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "arfe_nearest_add_fwd": (_i32, [_i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp]),
+    "arfe_nearest_add_fwd": (_i32, [_i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp]),
     "arfe_nearest_add_bwd": (_i32, [_i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp]),
     "arfe_subsample2": (_i32, [_i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
 }

@@ -211,9 +211,9 @@ int32_t arfe_convmap3x3_bwd_data(int32_t B, int32_t C, int32_t H, int32_t W, con
                                  float* dx, void* stream);
 int32_t arfe_convmap3x3_bwd_weight(int32_t B, int32_t C, int32_t H, int32_t W, const float* x, const float* dy,
                                    float* dw, float* db, void* workspace, void* stream);
-/* lat[B,C,H,W] += nearest(top[B,C,h,w] -> H x W); backward: dtop += nearest^T(dlat) */
+/* out[B,C,H,W] = lat + nearest(top[B,C,h,w] -> H x W) (out may alias lat); backward: dtop += nearest^T(dlat) */
 int32_t arfe_nearest_add_fwd(int32_t B, int32_t C, int32_t h, int32_t w, const float* top, int32_t H, int32_t W,
-                             float* lat, void* stream);
+                             const float* lat, float* out, void* stream);
 int32_t arfe_nearest_add_bwd(int32_t B, int32_t C, int32_t h, int32_t w, float* dtop, int32_t H, int32_t W,
                              const float* dlat, void* stream);
 /* backward == 0: out[B,C,(H-1)/2+1,(W-1)/2+1] = in[B,C,H,W][::2, ::2]; backward != 0: out[B,C,H,W] = scatter of in */
