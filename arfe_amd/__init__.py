@@ -1,7 +1,7 @@
 """arfe_amd — MI355X-native (gfx950) AR-FPN / AR-RFF forward+backward behind the mmdetection plugin surface.
 
 Public surface (names, ctor arguments and state_dict keys follow the reference):
-    NECKS['WFPNDualSpatial'], HEADS['MultiBBoxHead' | 'MultiRoIsBBoxHead' | 'StandardRoIHead'],
+    NECKS['WFPNDualSpatial' | 'FPN'], HEADS['MultiBBoxHead' | 'MultiRoIsBBoxHead' | 'StandardRoIHead'],
     ROI_EXTRACTORS['SingleRoIExtractor'], ops NonLocal2D / RoIAlign, build_neck / build_head / ...
 All arithmetic runs in libarfe_hip.so (include/arfe_hip.h); there is no CPU or PyTorch fallback.
 """
@@ -9,7 +9,7 @@ from .registry import (BACKBONES, DETECTORS, HEADS, LOSSES, NECKS, ROI_EXTRACTOR
                        build, build_from_cfg, build_head, build_neck, build_roi_extractor)
 from .cnn import ConvModule, constant_init, normal_init, xavier_init
 from .non_local import NonLocal2D
-from .necks import WFPNDualSpatial
+from .necks import FPN, WFPNDualSpatial
 from .roi_align import RoIAlign
 from .roi_heads import MultiBBoxHead, MultiRoIsBBoxHead, SingleRoIExtractor, StandardRoIHead, get_adaptive_scale_rois
 from .config import Config
@@ -17,6 +17,6 @@ from .config import Config
 __all__ = [
     'BACKBONES', 'DETECTORS', 'HEADS', 'LOSSES', 'NECKS', 'ROI_EXTRACTORS', 'SHARED_HEADS', 'Registry', 'build',
     'build_from_cfg', 'build_head', 'build_neck', 'build_roi_extractor', 'ConvModule', 'constant_init',
-    'normal_init', 'xavier_init', 'NonLocal2D', 'WFPNDualSpatial', 'RoIAlign', 'MultiBBoxHead',
+    'normal_init', 'xavier_init', 'NonLocal2D', 'WFPNDualSpatial', 'FPN', 'RoIAlign', 'MultiBBoxHead',
     'MultiRoIsBBoxHead', 'SingleRoIExtractor', 'StandardRoIHead', 'get_adaptive_scale_rois', 'Config',
 ]
