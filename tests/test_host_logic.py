@@ -132,6 +132,14 @@ def test_reference_configs_load_unchanged():
     assert cfg.model.neck[1] == dict(type='WFPNDualSpatial', in_channels=256, num_levels=5)
     neck = arfe_amd.build_neck(cfg.model.neck[1])
     assert neck.refine_level == 2
+    # the whole neck list of the flagship config builds: [FPN, WFPNDualSpatial] -> nn.Sequential (builder.py:14-18)
+    assert cfg.model.neck[0]['type'] == 'FPN'
+    fpn = arfe_amd.build_neck(cfg.model.neck[0])
+    assert fpn.num_outs == 5 and len(fpn.lateral_convs) == 4 and len(fpn.fpn_convs) == 4
+    assert set(dict(fpn.named_parameters())) == {f'{g}.{i}.conv.{p}' for g in ('lateral_convs', 'fpn_convs')
+                                                 for i in range(4) for p in ('weight', 'bias')}
+    both = arfe_amd.build_neck(cfg.model.neck)
+    assert [type(m).__name__ for m in both] == ['FPN', 'WFPNDualSpatial']
     roi_head = arfe_amd.build_head(cfg.model.roi_head)
     assert type(roi_head.bbox_head).__name__ == 'MultiRoIsBBoxHead'
     assert roi_head.bbox_roi_extractor.featmap_strides == [4, 8, 16, 32, 64]
