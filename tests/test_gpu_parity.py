@@ -404,6 +404,39 @@ def test_base_fpn_r50_sizes_match_oracle(O, dev):
         assert relerr(v.grad, pr[k].grad) <= TOL_GRAD, k
 
 
+def test_neck_sequence_fpn_then_arfpn_matches_oracle(O, dev):
+    """The flagship config's neck list [FPN, WFPNDualSpatial] built through the registry (nn.Sequential, builder.py:14-18):
+    backbone-shaped inputs -> base FPN -> AR-FPN, forward and gradients down to the backbone features, against the
+    composition of the two oracles."""
+    import arfe_amd
+    g = torch.Generator().manual_seed(31)
+    in_channels, sizes = (8, 16, 24, 32), ((40, 64), (20, 32), (10, 16), (5, 8))
+    neck = arfe_amd.build_neck([dict(type='FPN', in_channels=list(in_channels), out_channels=16, num_outs=5),
+                                dict(type='WFPNDualSpatial', in_channels=16, num_levels=5)]).to(dev)
+    for m in neck:
+        m.init_weights()
+    with torch.no_grad():
+        for n, p in neck.named_parameters():
+            if n.endswith('bias'):
+                p.copy_(torch.randn(p.shape, generator=g).to(dev) * 0.1)
+    xs_cpu = [torch.randn(2, c, h, w, generator=g) for c, (h, w) in zip(in_channels, sizes)]
+    pf = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in neck[0].state_dict().items()}
+    pa = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in neck[1].state_dict().items()}
+    xr = [x.clone().requires_grad_(True) for x in xs_cpu]
+    ref = O.arfpn_forward(list(O.fpn_forward(xr, pf, 5)), pa, refine_level=2)
+    cots = [torch.randn(o.shape, generator=g) for o in ref]
+    sum((o * c).sum() for o, c in zip(ref, cots)).backward()
+    xs = [x.clone().to(dev).requires_grad_(True) for x in xs_cpu]
+    outs = neck(xs)
+    sum((o * c.to(dev)).sum() for o, c in zip(outs, cots)).backward()
+    for i, o in enumerate(outs):
+        assert relerr(o, ref[i].detach()) <= TOL, i
+    for i in range(len(xs)):
+        assert relerr(xs[i].grad, xr[i].grad) <= TOL_GRAD, i
+    for k, v in neck[0].named_parameters():
+        assert relerr(v.grad, pf[k].grad) <= TOL_GRAD, k
+
+
 def test_empty_roi_set_flows_through_extractor_and_head(dev):
     """R = 0 (an image batch without proposals) must give empty outputs and zero gradients, not a crash."""
     import arfe_amd
