@@ -426,14 +426,15 @@ __global__ __launch_bounds__(256) void roialign_fwd_sep_kernel(RoiLevels L, RoiS
 }
 
 
-// One workgroup = (16x16 feature tile, RB_CC channels).  RoIs of the tile's list are taken RB_NB at a time so
-// that the dependent global reads of a batch (list -> roi -> G) overlap, and the column contraction
-//   T[c][ph][x] = sum_pw wx[pw][x] G[c][ph][pw]
-// is done once per batch in LDS instead of once per pixel row; a pixel then needs sum_ph wy[ph][y] T[c][ph][x].
+// One workgroup = (16x16 feature tile, RB_CC channels).  RoIs of the tile's list are taken RB_NB at a time: their
+// gradient blocks and 1-D weights (read one batch ahead, the list entries two) are staged in LDS, then each wave
+// contracts its 4 channels on the matrix pipe:
+//   C:  T[(c,ph)][x] = sum_pw G[c][ph][pw] wx[pw][x]      D:  dX_c[y][x] += sum_ph wy[y][ph] T_c[ph][x]
+// (separable form of the bilinear scatter; every feature element is written once, no atomics unless a long list is cut).
 constexpr int RB_NB = 4;
 constexpr int RB_SEGS = 4;        // slices of a long RoI list
 constexpr int RB_SEG_MIN = 32;    // lists up to this length stay in one workgroup (plain stores)
-static_assert(RB_CC == 16 && RT == 16, "phase C maps the 16 lane-groups of a workgroup to the 16 channels of a chunk");
+static_assert(RB_CC == 16 && RT == 16, "the MFMA tiles are 16x16: a wave owns 4 of the 16 channels, a tile is 16x16 pixels");
 __global__ __launch_bounds__(256) void roialign_bwd_tiles_kernel(RoiLevels L, RoiSets S, RoiTileTable T, int P, int sample_num,
                                                                  const float* __restrict__ gout, int64_t g_roi_stride,
                                                                  const int* __restrict__ offsets, const int* __restrict__ list,
@@ -461,8 +462,7 @@ __global__ __launch_bounds__(256) void roialign_bwd_tiles_kernel(RoiLevels L, Ro
     const float scale = L.scale[lvl];
     const int c0 = (int)(blockIdx.x % (unsigned)nchunks) * RB_CC;
     const int ncc = L.C - c0 < RB_CC ? L.C - c0 : RB_CC;
-    const int tid = threadIdx.x, py = tid >> 4, px = tid & 15;
-    const int y = ty * RT + py, x = tx * RT + px;
+    const int tid = threadIdx.x;
     // Both contractions run on the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32).  Wave v owns channels 4v..4v+3 of the chunk:
     //   C: T[(c,ph)][x] = sum_pw G[(c,ph)][pw] wx[pw][x]   (two channels = 14 of the 16 rows of one M tile, K = 8)
     //   D: dX_c[y][x] += sum_ph wy[y][ph] T_c[ph][x]        (accumulated over the RoIs of the list in the MFMA D tile)
@@ -479,7 +479,6 @@ __global__ __launch_bounds__(256) void roialign_bwd_tiles_kernel(RoiLevels L, Ro
     const int per_seg = (lend - lbeg + nseg - 1) / nseg;
     const int beg = lbeg + seg * per_seg;
     const int end = beg + per_seg < lend ? beg + per_seg : lend;
-    const int grp = tid >> 4;                  // phase C role: channel c0+grp, all 7 bin rows, column px
     // phase A/B roles: thread t < 112 -> weight of (tile row t/7, bin t%7); 128 <= t < 240 -> (tile column, bin);
     // every thread copies up to RB_GPT floats of each RoI's 16x49 gradient block
     const bool a_role = tid < RT * 7 || (tid >= 128 && tid < 128 + RT * 7);
