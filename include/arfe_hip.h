@@ -57,7 +57,7 @@ int32_t arfe_fpn_gather_fwd(const arfe_pyramid_t* pyr, const float* const* x, fl
 
 /* gate maps (:119-121 + mmcv ConvModule's ReLU): a_i = tanh(relu(conv3x3(x_i; w1_i) + b1_i)),
  * b_i likewise with (w2_i, b2_i); w*_i is [1,C,3,3], b*_i is [1]; a_i, b_i are [B,1,h_i,w_i].
- * workspace: arfe_fpn_gatemap_workspace_bytes(pyr) bytes (per-channel-group partial sums). */
+ * workspace: arfe_fpn_gatemap_workspace_bytes(pyr) bytes (the 18 per-(gate, tap) product maps + packed weights). */
 int64_t arfe_fpn_gatemap_workspace_bytes(const arfe_pyramid_t* pyr);
 int32_t arfe_fpn_gatemap_fwd(const arfe_pyramid_t* pyr, const float* const* x, const float* const* w1,
                              const float* const* b1, const float* const* w2, const float* const* b2,
