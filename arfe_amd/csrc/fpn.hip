@@ -229,41 +229,79 @@ struct QuadTable {
     int wq[NL_];
 };
 
-__global__ __launch_bounds__(256) void fpn_scatter_fwd_kernel(Levels lv, QuadTable qt, LevelPtrs x, const float* __restrict__ bsf,
+struct BlockQuadTable {       // pixel quads (B*h*ceil(w/4)) of each level, in whole 64-quad blocks
+    int first_blk[NL_ + 1];
+    int64_t quads[NL_];
+    int wq[NL_];
+};
+
+// out = x + nearest(bsf) * (a + b).  Workgroup = 64 pixel quads (block-aligned per level, so the level is a function
+// of blockIdx) x 4 waves; a wave walks SC_NB batches of SC_CG channels of its quad column: the gate quads and the
+// nearest indices are computed once per thread, and the reads of a batch are issued before its stores.
+constexpr int SC_CG = 4, SC_NB = 4;
+__global__ __launch_bounds__(256) void fpn_scatter_fwd_kernel(Levels lv, BlockQuadTable bt, LevelPtrs x, const float* __restrict__ bsf,
                                                               LevelPtrs a, LevelPtrs b, LevelMutPtrs out) {
-    int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= qt.first[lv.n]) return;
+    const int lq = threadIdx.x & 63, cw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int lvl = 0;
-    while (lvl + 1 < lv.n && q >= qt.first[lvl + 1]) ++lvl;
-    q -= qt.first[lvl];
-    const int h = lv.H[lvl], w = lv.W[lvl], wq = qt.wq[lvl];
+    while (lvl + 1 < lv.n && (int)blockIdx.x >= bt.first_blk[lvl + 1]) ++lvl;
+    const unsigned q_blk = (unsigned)((int)blockIdx.x - bt.first_blk[lvl]) * 64u;
+    unsigned q = q_blk + lq;
+    const bool active = q < (unsigned)bt.quads[lvl];
+    if (!active) q = q_blk;
+    const int h = lv.H[lvl], w = lv.W[lvl], wq = bt.wq[lvl];
     const int hr = lv.H[lv.r], wr = lv.W[lv.r];
-    const int x0 = (int)(q % wq) * 4;
-    const int y = (int)((q / wq) % h);
-    const int64_t bc = q / ((int64_t)wq * h);
-    const int bi = (int)(bc / lv.C);
+    const unsigned qrow = q / (unsigned)wq;
+    const int x0 = (int)(q - qrow * (unsigned)wq) * 4;
+    const int bi = (int)(qrow / (unsigned)h);
+    const int y = (int)(qrow - (unsigned)bi * (unsigned)h);
+    const bool full = x0 + 3 < w;
+    const int e1 = x0 + 1 < w ? 1 : 0, e2 = x0 + 2 < w ? 2 : e1, e3 = x0 + 3 < w ? 3 : e2;
     const float sy_scale = nearest_scale(hr, h), sx_scale = nearest_scale(wr, w);
     const int sy = nearest_src(y, hr, sy_scale);
-    const float* brow = bsf + (bc * hr + sy) * (int64_t)wr;
-    const int64_t off = (bc * h + y) * (int64_t)w + x0;
-    const int64_t moff = ((int64_t)bi * h + y) * w + x0;
-    const float* xp = x.p[lvl] + off;
-    float* op = out.p[lvl] + off;
-    if (x0 + 3 < w) {
-        float4_u xv = *reinterpret_cast<const float4_u*>(xp);
-        float4_u av = *reinterpret_cast<const float4_u*>(a.p[lvl] + moff);
-        float4_u bv = *reinterpret_cast<const float4_u*>(b.p[lvl] + moff);
-        float4_u o;
+    const int sx[4] = {nearest_src(x0, wr, sx_scale), nearest_src(x0 + e1, wr, sx_scale), nearest_src(x0 + e2, wr, sx_scale),
+                       nearest_src(x0 + e3, wr, sx_scale)};
+    float s4[4];
+    {
+        const int64_t moff = ((int64_t)bi * h + y) * w + x0;
+        const float* ap = a.p[lvl] + moff;
+        const float* bp = b.p[lvl] + moff;
+        s4[0] = ap[0] + bp[0]; s4[1] = ap[e1] + bp[e1]; s4[2] = ap[e2] + bp[e2]; s4[3] = ap[e3] + bp[e3];
+    }
+    const int c_wave = (blockIdx.y * 4 + cw) * (SC_CG * SC_NB);
+    const int c_last = lv.C - 1;
+#pragma unroll 1
+    for (int nb = 0; nb < SC_NB; ++nb) {
+        const int c_first = c_wave + nb * SC_CG;
+        if (c_first >= lv.C) break;
+        float xv[SC_CG][4], u[SC_CG][4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float u = brow[nearest_src(x0 + e, wr, sx_scale)];
-            o[e] = xv[e] + u * (av[e] + bv[e]);
+        for (int cj = 0; cj < SC_CG; ++cj) {
+            const int c = c_first + cj < lv.C ? c_first + cj : c_last;
+            const int64_t bc = (int64_t)bi * lv.C + c;
+            const float* xp = x.p[lvl] + (bc * h + y) * (int64_t)w + x0;
+            const float* brow = bsf + (bc * hr + sy) * (int64_t)wr;
+            if (full) {
+                const float4_u v = *reinterpret_cast<const float4_u*>(xp);
+                xv[cj][0] = v[0]; xv[cj][1] = v[1]; xv[cj][2] = v[2]; xv[cj][3] = v[3];
+            } else {
+                xv[cj][0] = xp[0]; xv[cj][1] = xp[e1]; xv[cj][2] = xp[e2]; xv[cj][3] = xp[e3];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) u[cj][e] = brow[sx[e]];
         }
-        *reinterpret_cast<float4_u*>(op) = o;
-    } else {
-        for (int e = 0; e < 4 && x0 + e < w; ++e) {
-            const float u = brow[nearest_src(x0 + e, wr, sx_scale)];
-            op[e] = xp[e] + u * (a.p[lvl][moff + e] + b.p[lvl][moff + e]);
+#pragma unroll
+        for (int cj = 0; cj < SC_CG; ++cj) {
+            if (!active || c_first + cj >= lv.C) continue;
+            float* op = out.p[lvl] + (((int64_t)bi * lv.C + c_first + cj) * h + y) * (int64_t)w + x0;
+            if (full) {
+                float4_u o = {xv[cj][0] + u[cj][0] * s4[0], xv[cj][1] + u[cj][1] * s4[1], xv[cj][2] + u[cj][2] * s4[2],
+                              xv[cj][3] + u[cj][3] * s4[3]};
+                *reinterpret_cast<float4_u*>(op) = o;
+            } else {
+                op[0] = xv[cj][0] + u[cj][0] * s4[0];
+                if (x0 + 1 < w) op[1] = xv[cj][1] + u[cj][1] * s4[1];
+                if (x0 + 2 < w) op[2] = xv[cj][2] + u[cj][2] * s4[2];
+            }
         }
     }
 }
@@ -390,11 +428,6 @@ __global__ __launch_bounds__(256) void fpn_scatter_bwd_dbsf_kernel(Levels lv, Le
 // =========================================================================================================
 constexpr int IB_CG = 4;   // channels whose reads are in flight together
 constexpr int IB_NB = 4;   // such batches per wave (amortises the neighbourhood reads of the two maps)
-struct BlockQuadTable {       // pixel quads (B*h*ceil(w/4)) of each level, in whole 64-quad blocks
-    int first_blk[NL_ + 1];
-    int64_t quads[NL_];
-    int wq[NL_];
-};
 // Each index regime is its own instantiation so that only its paths are compiled in (all paths in one kernel made
 // 167 KB of code at 256 VGPRs): levels with an exact power-of-two ratio to the refine level use shifts only.
 // MODE 0 = POW2 (shift-only paths), 1 = generic level >= refine (nearest^T), 2 = generic level < refine (pool windows)
@@ -923,9 +956,19 @@ extern "C" int32_t arfe_fpn_scatter_fwd(const arfe_pyramid_t* pyr, const float* 
     ARFE_CHECK_ARG(fill_ptrs(xp, x, lv.n) && fill_ptrs(ap, a, lv.n) && fill_ptrs(bp, b, lv.n) &&
                        fill_ptrs(op, out, lv.n) && bsf,
                    ARFE_ERR_ARG, "fpn_scatter_fwd: null pointer");
-    QuadTable qt = make_quad_table(lv);
-    hipLaunchKernelGGL(fpn_scatter_fwd_kernel, dim3((unsigned)cdiv64(qt.first[lv.n], 256)), dim3(256), 0,
-                       as_stream(stream), lv, qt, xp, bsf, ap, bp, op);
+    BlockQuadTable bt;
+    int nblk = 0;
+    for (int i = 0; i <= NL_; ++i) {
+        bt.first_blk[i] = nblk;
+        if (i < NL_) {
+            bt.wq[i] = i < lv.n ? cdiv(lv.W[i], 4) : 0;
+            bt.quads[i] = i < lv.n ? (int64_t)lv.B * lv.H[i] * bt.wq[i] : 0;
+            ARFE_CHECK_ARG(bt.quads[i] < (int64_t)1 << 31, ARFE_ERR_ARG, "fpn_scatter_fwd: level %d too large", i);
+            nblk += (int)cdiv64(bt.quads[i], 64);
+        }
+    }
+    hipLaunchKernelGGL(fpn_scatter_fwd_kernel, dim3(nblk, cdiv(lv.C, 4 * SC_CG * SC_NB)), dim3(256), 0, as_stream(stream), lv,
+                       bt, xp, bsf, ap, bp, op);
     ARFE_CHECK_LAUNCH();
     return ARFE_OK;
 }
