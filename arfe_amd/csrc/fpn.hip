@@ -344,11 +344,14 @@ __global__ __launch_bounds__(256) void fpn_scatter_bwd_maps_kernel(Levels lv, Pi
         const float* gp = gout.p[lvl] + (((int64_t)bi * lv.C + c_begin) * h + y) * w + x0;
         const float* bp = bsf + (((int64_t)bi * lv.C + c_begin) * hr + sy) * wr;
         const int64_t gstep = (int64_t)h * w, bstep = (int64_t)hr * wr;
-#pragma unroll 4
+        // clamped element offsets for the row-end quad (its lanes past the row are never stored): no branch in the
+        // channel loop, eight channels' reads in flight
+        const int e1 = x0 + 1 < w ? 1 : 0, e2 = x0 + 2 < w ? 2 : e1, e3 = x0 + 3 < w ? 3 : e2;
+#pragma unroll 8
         for (int c = c_begin; c < c_end; ++c) {
-            float4_u gv = {0.f, 0.f, 0.f, 0.f};
+            float4_u gv;
             if (full) gv = *reinterpret_cast<const float4_u*>(gp);
-            else for (int e = 0; e < 4 && x0 + e < w; ++e) gv[e] = gp[e];
+            else { gv[0] = gp[0]; gv[1] = gp[e1]; gv[2] = gp[e2]; gv[3] = gp[e3]; }
 #pragma unroll
             for (int e = 0; e < 4; ++e) dm[e] += gv[e] * bp[sx[e]];
             gp += gstep; bp += bstep;
@@ -371,17 +374,24 @@ __global__ __launch_bounds__(256) void fpn_scatter_bwd_maps_kernel(Levels lv, Pi
 }
 
 // backward B: dbsf[b,c,sy,sx] = sum_i sum_{dst -> (sy,sx)} g_i[c,dst] (a_i + b_i)[dst]
+constexpr int DB_CG = 4;       // channels per thread: the gate quads (a + b) of a window are read once for all of them
 __global__ __launch_bounds__(256) void fpn_scatter_bwd_dbsf_kernel(Levels lv, LevelPtrs gout, LevelPtrs a, LevelPtrs b,
                                                                    float* __restrict__ dbsf) {
     const int hr = lv.H[lv.r], wr = lv.W[lv.r];
-    const int64_t total = (int64_t)lv.B * lv.C * hr * wr;
+    const int cgs = (lv.C + DB_CG - 1) / DB_CG;
+    const int64_t total = (int64_t)lv.B * cgs * hr * wr;
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const int sx = (int)(idx % wr);
     const int sy = (int)((idx / wr) % hr);
-    const int64_t bc = idx / ((int64_t)wr * hr);
-    const int bi = (int)(bc / lv.C);
-    float acc = 0.f;
+    const int64_t bg = idx / ((int64_t)wr * hr);
+    const int bi = (int)(bg / cgs), c0 = (int)(bg - (int64_t)bi * cgs) * DB_CG;
+    float acc[DB_CG];
+#pragma unroll
+    for (int j = 0; j < DB_CG; ++j) acc[j] = 0.f;
+    int cc[DB_CG];
+#pragma unroll
+    for (int j = 0; j < DB_CG; ++j) cc[j] = c0 + j < lv.C ? c0 + j : lv.C - 1;
     for (int i = 0; i < lv.n; ++i) {
         const int h = lv.H[i], w = lv.W[i];
         int y0, y1, x0, x1;
@@ -397,27 +407,36 @@ __global__ __launch_bounds__(256) void fpn_scatter_bwd_dbsf_kernel(Levels lv, Le
             y0 = nearest_dst_begin(sy, hr, h, ys); y1 = nearest_dst_begin(sy + 1, hr, h, ys);
             x0 = nearest_dst_begin(sx, wr, w, xs); x1 = nearest_dst_begin(sx + 1, wr, w, xs);
         }
-        const float* gp = gout.p[i] + bc * (int64_t)h * w;
-        const float* ap = a.p[i] + (int64_t)bi * h * w;
-        const float* bp = b.p[i] + (int64_t)bi * h * w;
+        const int64_t plane = (int64_t)h * w;
+        const float* gp = gout.p[i] + (int64_t)bi * lv.C * plane;
+        const float* ap = a.p[i] + (int64_t)bi * plane;
+        const float* bp = b.p[i] + (int64_t)bi * plane;
         if (x1 - x0 == 4) {
             for (int yy = y0; yy < y1; ++yy) {
                 const int64_t o = (int64_t)yy * w + x0;
-                float4_u gv = *reinterpret_cast<const float4_u*>(gp + o);
-                float4_u av = *reinterpret_cast<const float4_u*>(ap + o);
-                float4_u bv = *reinterpret_cast<const float4_u*>(bp + o);
+                const float4_u av = *reinterpret_cast<const float4_u*>(ap + o);
+                const float4_u bv = *reinterpret_cast<const float4_u*>(bp + o);
+                float4_u gv[DB_CG];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc += gv[e] * (av[e] + bv[e]);
+                for (int j = 0; j < DB_CG; ++j) gv[j] = *reinterpret_cast<const float4_u*>(gp + cc[j] * plane + o);
+#pragma unroll
+                for (int j = 0; j < DB_CG; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[j] += gv[j][e] * (av[e] + bv[e]);
             }
         } else {
             for (int yy = y0; yy < y1; ++yy)
                 for (int xx = x0; xx < x1; ++xx) {
                     const int64_t o = (int64_t)yy * w + xx;
-                    acc += gp[o] * (ap[o] + bp[o]);
+                    const float sv = ap[o] + bp[o];
+#pragma unroll
+                    for (int j = 0; j < DB_CG; ++j) acc[j] += gp[cc[j] * plane + o] * sv;
                 }
         }
     }
-    dbsf[idx] = acc;
+#pragma unroll
+    for (int j = 0; j < DB_CG; ++j)
+        if (c0 + j < lv.C) dbsf[(((int64_t)bi * lv.C + c0 + j) * hr + sy) * wr + sx] = acc[j];
 }
 
 // =========================================================================================================
@@ -989,7 +1008,7 @@ extern "C" int32_t arfe_fpn_scatter_bwd(const arfe_pyramid_t* pyr, const float* 
     hipLaunchKernelGGL(fpn_scatter_bwd_maps_kernel, dim3((unsigned)cdiv64(pt.first[lv.n], 64)), dim3(256), 0, st, lv, pt,
                        gp, bsf, ap, bp, dap, dbp);
     ARFE_CHECK_LAUNCH();
-    const int64_t total = (int64_t)lv.B * lv.C * lv.H[lv.r] * lv.W[lv.r];
+    const int64_t total = (int64_t)lv.B * cdiv(lv.C, DB_CG) * lv.H[lv.r] * lv.W[lv.r];
     hipLaunchKernelGGL(fpn_scatter_bwd_dbsf_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, lv, gp, ap, bp,
                        dbsf);
     ARFE_CHECK_LAUNCH();
