@@ -338,8 +338,12 @@ __global__ __launch_bounds__(256) void fpn_scatter_bwd_maps_kernel(Levels lv, Pi
         int sx[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) sx[e] = nearest_src(x0 + e < w ? x0 + e : w - 1, wr, sx_scale);
-        const int cq = (lv.C + 3) / 4;
-        const int c_begin = quarter * cq, c_end = c_begin + cq < lv.C ? c_begin + cq : lv.C;
+        // channels: gridDim.y chunks (more workgroups in flight than the 700 pixel blocks alone), a quarter of a chunk per wave
+        const int cchunk = (lv.C + (int)gridDim.y - 1) / (int)gridDim.y;
+        const int ch0 = blockIdx.y * cchunk, ch1 = ch0 + cchunk < lv.C ? ch0 + cchunk : lv.C;
+        const int cq = (ch1 - ch0 + 3) / 4;
+        const int c_begin = ch0 + quarter * cq < ch1 ? ch0 + quarter * cq : ch1;
+        const int c_end = c_begin + cq < ch1 ? c_begin + cq : ch1;
         const bool full = x0 + 3 < w;
         const float* gp = gout.p[lvl] + (((int64_t)bi * lv.C + c_begin) * h + y) * w + x0;
         const float* bp = bsf + (((int64_t)bi * lv.C + c_begin) * hr + sy) * wr;
@@ -366,14 +370,29 @@ __global__ __launch_bounds__(256) void fpn_scatter_bwd_maps_kernel(Levels lv, Pi
         const int64_t moff = ((int64_t)bi * h + y) * w + x0;
         for (int e = 0; e < 4 && x0 + e < w; ++e) {
             const float d = ((dm[e] + red[0][lq][e]) + red[1][lq][e]) + red[2][lq][e];
-            const float av = a.p[lvl][moff + e], bv = b.p[lvl][moff + e];
-            dpa.p[lvl][moff + e] = av > 0.f ? d * (1.f - av * av) : 0.f;
-            dpb.p[lvl][moff + e] = bv > 0.f ? d * (1.f - bv * bv) : 0.f;
+            if (gridDim.y > 1) {                 // partial sum over this chunk's channels: dpa collects dm (zeroed before)
+                unsafeAtomicAdd(dpa.p[lvl] + moff + e, d);
+            } else {
+                const float av = a.p[lvl][moff + e], bv = b.p[lvl][moff + e];
+                dpa.p[lvl][moff + e] = av > 0.f ? d * (1.f - av * av) : 0.f;
+                dpb.p[lvl][moff + e] = bv > 0.f ? d * (1.f - bv * bv) : 0.f;
+            }
         }
     }
 }
+// dpa holds dm = sum_c g * nearest(bsf): turn it into the two pre-activation gradients (tanh' * relu')
+__global__ void fpn_scatter_bwd_maps_finish_kernel(Levels lv, TileTable tt, LevelPtrs a, LevelPtrs b, LevelMutPtrs dpa,
+                                                   LevelMutPtrs dpb) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= tt.px_off[lv.n]) return;
+    int lvl = 0;
+    while (lvl + 1 < lv.n && i >= tt.px_off[lvl + 1]) ++lvl;
+    const int64_t o = i - tt.px_off[lvl];
+    const float d = dpa.p[lvl][o], av = a.p[lvl][o], bv = b.p[lvl][o];
+    dpa.p[lvl][o] = av > 0.f ? d * (1.f - av * av) : 0.f;
+    dpb.p[lvl][o] = bv > 0.f ? d * (1.f - bv * bv) : 0.f;
+}
 
-// backward B: dbsf[b,c,sy,sx] = sum_i sum_{dst -> (sy,sx)} g_i[c,dst] (a_i + b_i)[dst]
 constexpr int DB_CG = 4;       // channels per thread: the gate quads (a + b) of a window are read once for all of them
 __global__ __launch_bounds__(256) void fpn_scatter_bwd_dbsf_kernel(Levels lv, LevelPtrs gout, LevelPtrs a, LevelPtrs b,
                                                                    float* __restrict__ dbsf) {
@@ -1005,9 +1024,22 @@ extern "C" int32_t arfe_fpn_scatter_bwd(const arfe_pyramid_t* pyr, const float* 
                    ARFE_ERR_ARG, "fpn_scatter_bwd: null pointer");
     hipStream_t st = as_stream(stream);
     PixQuadTable pt = make_pixquad_table(lv);
-    hipLaunchKernelGGL(fpn_scatter_bwd_maps_kernel, dim3((unsigned)cdiv64(pt.first[lv.n], 64)), dim3(256), 0, st, lv, pt,
-                       gp, bsf, ap, bp, dap, dbp);
+    const int nchunk = lv.C >= 64 ? 4 : 1;
+    if (nchunk > 1) {
+        ZeroList z;
+        for (int i = 0; i < lv.n; ++i) z.add(dap.p[i], (int64_t)lv.B * lv.H[i] * lv.W[i]);
+        rc = zero_buffers(z, st);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(fpn_scatter_bwd_maps_kernel, dim3((unsigned)cdiv64(pt.first[lv.n], 64), nchunk), dim3(256), 0, st, lv,
+                       pt, gp, bsf, ap, bp, dap, dbp);
     ARFE_CHECK_LAUNCH();
+    if (nchunk > 1) {
+        TileTable tt = make_tile_table(lv);
+        hipLaunchKernelGGL(fpn_scatter_bwd_maps_finish_kernel, dim3((unsigned)cdiv64(tt.px_off[lv.n], 256)), dim3(256), 0, st,
+                           lv, tt, ap, bp, dap, dbp);
+        ARFE_CHECK_LAUNCH();
+    }
     const int64_t total = (int64_t)lv.B * cdiv(lv.C, DB_CG) * lv.H[lv.r] * lv.W[lv.r];
     hipLaunchKernelGGL(fpn_scatter_bwd_dbsf_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, lv, gp, ap, bp,
                        dbsf);
