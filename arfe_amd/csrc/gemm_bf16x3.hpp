@@ -367,7 +367,22 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_large_kernel(GemmDims d, L
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
-    const int z = blockIdx.z;
+    // batch and K-slice of this workgroup.  Per-batch reduction lengths (zk_on): gridDim.y lists exactly the (batch, slice)
+    // pairs - first the class-1 batches, then the class-0 ones - so that no workgroup is launched only to exit
+    // (a grid with 24 idle workgroups beyond the 256 CUs ran the 246 working ones in two rounds).
+    int z = blockIdx.z, slice = blockIdx.y;
+    if (d.zk_on) {
+        int p = blockIdx.y, n1 = __builtin_popcount(d.zk_class);
+        const bool cls = p < n1 * d.zk_splits1;
+        if (!cls) p -= n1 * d.zk_splits1;
+        const int sp = cls ? d.zk_splits1 : d.zk_splits0;
+        int zi = p / sp;
+        slice = p - zi * sp;
+        z = 0;
+        for (int b = 0; b < 32; ++b) {                  // zi-th batch whose class bit equals cls
+            if ((((d.zk_class >> b) & 1u) != 0) == cls) { if (zi == 0) { z = b; break; } --zi; }
+        }
+    }
 
     int ntiles = d.tiles_m * d.tiles_n;
     int bid = blockIdx.x;
@@ -379,11 +394,17 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_large_kernel(GemmDims d, L
     const int m0 = tm * XL_BM, n0 = tn * XL_BN;
 
     const int ksteps_per_kb = (d.K + XB_BK - 1) / XB_BK;
-    const int per = (d.ksteps_total + d.splitk - 1) / d.splitk;
-    const int s_begin = blockIdx.y * per;
+    int kst = d.ksteps_total, spl = d.splitk;
+    if (d.zk_on) {                       // per-batch reduction length / slice count
+        const bool cls = (d.zk_class >> z) & 1u;
+        kst = cls ? d.zk_steps1 : d.zk_steps0;
+        spl = cls ? d.zk_splits1 : d.zk_splits0;
+    }
+    const int per = (kst + spl - 1) / spl;
+    const int s_begin = slice * per;
     int s_end = s_begin + per;
-    if (s_end > d.ksteps_total) s_end = d.ksteps_total;
-    const bool first_split = (blockIdx.y == 0);
+    if (s_end > kst) s_end = kst;
+    const bool first_split = (slice == 0);
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -749,7 +770,8 @@ static inline bool plan_large_tile(int M, int N, int batch, int ksteps, int* spl
 
 template <class LA, class LB, class EPI>
 static inline int32_t launch_gemm_auto(int M, int N, int K, int kb_count, int batch, int splitk, LA la, LB lb, EPI epi,
-                                       hipStream_t stream, bool exact = false, bool kb_inner = false) {
+                                       hipStream_t stream, bool exact = false, bool kb_inner = false,
+                                       const GemmDims* zvar = nullptr) {
     if (gemm_use_f32()) return launch_gemm(M, N, K, kb_count, batch, splitk, la, lb, epi, stream, kb_inner);
     if (M <= 0 || N <= 0 || batch <= 0) return ARFE_OK;
     if (exact) {        // fp32-grade products from six bf16 MFMAs (see gemm_bf16x6_kernel)
@@ -784,7 +806,7 @@ static inline int32_t launch_gemm_auto(int M, int N, int K, int kb_count, int ba
             else if (use_large) splitk_large = splitk;
         }
     }
-    if (use_large && N % XN_BN == 0 && d.K % XB_BK == 0) {
+    if (use_large && !zvar && N % XN_BN == 0 && d.K % XB_BK == 0) {
         // 224-wide tiles when they fill the chip's rounds better (cost in units of one 256x256 tile's time)
         const int64_t t256 = (int64_t)cdiv(M, XL_BM) * cdiv(N, XL_BN) * batch * splitk_large;
         const int64_t t224 = (int64_t)cdiv(M, XL_BM) * (N / XN_BN) * batch * splitk_large;
@@ -810,9 +832,23 @@ static inline int32_t launch_gemm_auto(int M, int N, int K, int kb_count, int ba
             return ARFE_OK;
         }
     }
+    if (zvar && !use_large) {
+        set_error("gemm: per-batch reduction lengths need the large-tile kernel (M=%d N=%d)", M, N);
+        return ARFE_ERR_ARG;
+    }
     if (use_large) {
         splitk = splitk_large;
         d.splitk = splitk;
+        if (zvar) {                      // the caller planned steps and slices per batch (plan_large_tile said yes)
+            d.zk_on = 1;
+            d.zk_class = zvar->zk_class;
+            d.zk_steps0 = zvar->zk_steps0; d.zk_steps1 = zvar->zk_steps1;
+            d.zk_splits0 = zvar->zk_splits0; d.zk_splits1 = zvar->zk_splits1;
+            const int n1 = __builtin_popcount(d.zk_class & ((1u << batch) - 1u));
+            splitk = n1 * d.zk_splits1 + (batch - n1) * d.zk_splits0;      // gridDim.y = every (batch, slice) pair
+            d.splitk = splitk;
+            batch = 1;                                                     // gridDim.z: the batch is decoded from y
+        }
         d.tiles_m = cdiv(M, XL_BM); d.tiles_n = cdiv(N, XL_BN);
         static bool attr_set = false;      // per instantiation: opt in to the full 160 KB of LDS once
         if (!attr_set) {

@@ -30,6 +30,12 @@ struct GemmDims {
     int splitk;         // gridDim.y
     int ksteps_total;   // kb_count * ceil(K / BK)
     int kb_inner;       // 1: iterate k-batches innermost
+    // optional per-batch reduction length (large-tile kernel only): batch z belongs to class (zk_class >> z) & 1 and runs
+    // zk_steps<class> K-steps cut into zk_splits<class> slices (gridDim.y = the larger count).  Scalars, not arrays: an
+    // array indexed by blockIdx.z would move the whole argument struct to scratch memory.
+    int zk_on = 0;
+    unsigned zk_class = 0;
+    int zk_steps0 = 0, zk_steps1 = 0, zk_splits0 = 0, zk_splits1 = 0;
 };
 
 // ---- operand loaders: return A(m,k) / B(k,n) for batch z and k-batch kb, 0 outside the matrix ------------

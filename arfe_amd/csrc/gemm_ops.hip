@@ -72,74 +72,74 @@ struct EpiConv {       // y[r*roi_stride + co*49 + p] = act(v + bias[co]) * [mas
 
 // Weight gradient of the 3x3 conv: reduction index k' = r*56 + p with the 49 pixels of an RoI padded to 7 octets
 // (p >= 49 is zero), so a k-octet never straddles two RoIs: K' = R*56.
-constexpr int WG_PAD = 56;
-struct WgradA {        // A(m=co, k') = dy[r*roi_stride + co*49 + p]
-    const float* dy; int64_t roi_stride; int Cout, R;
+// Weight gradient of the 3x3 convs: dWp[tap][co][ci] = sum_{r, p valid under tap} dy[r][co][p] * x[r][ci][p + shift(tap)].
+// The reduction index k' is row-structured: (RoI r, pixel row among the tap's VALID output rows, 8 slots), slot j < 7 =
+// pixel column j, slot 7 = zero.  A tap with dy != 0 has 6 valid rows, so its K is 6/7 of the others' (per-batch K of the
+// large-tile kernel; `uniform` = every tap walks 7 rows per RoI and masks the missing one, for the other kernels).
+// An octet is one contiguous 8-float window in both operands; column validity (dx != 0) is one constant mask on B.
+__device__ __forceinline__ void wg_tap_rows(int z, int& py0, int& nh) {
+    const int dy = z / 3 - 1;
+    py0 = dy < 0 ? 1 : 0;
+    nh = dy == 0 ? 7 : 6;
+}
+struct WgradA {        // A(m=co, k') = dy[r*roi_stride + co*49 + py*7 + j]
+    const float* dy; int64_t roi_stride; int Cout, R, uniform;
     static constexpr bool kfast = true;
-    __device__ __forceinline__ float operator()(int, int, int m, int k) const {
-        const int r = k / WG_PAD, p = k - r * WG_PAD;
-        if (m >= Cout || r >= R || p >= 49) return 0.f;
-        return dy[(int64_t)r * roi_stride + m * 49 + p];
+    __device__ __forceinline__ float operator()(int z, int, int m, int k) const {
+        int py0, nh; wg_tap_rows(z, py0, nh);
+        const int per = uniform ? 7 : nh;
+        const int o8 = k >> 3, j = k & 7, ri = o8 / per, rw = o8 - ri * per;
+        if (m >= Cout || ri >= R || rw >= nh || j >= 7) return 0.f;
+        return dy[(int64_t)ri * roi_stride + m * 49 + (py0 + rw) * 7 + j];
     }
     struct Row { const float* q; bool ok; };
     __device__ __forceinline__ Row row(int, int m) const { return Row{dy + (m < Cout ? m : Cout - 1) * 49, m < Cout}; }
     template <bool FULLK>
-    __device__ __forceinline__ void load8(const Row& r, int, int, int k0, float (&v)[8]) const {
-        const int o8 = k0 >> 3, ri = o8 / 7, oc = o8 - ri * 7;          // octet oc of RoI ri
-        const bool ok = r.ok && ri < R;
+    __device__ __forceinline__ void load8(const Row& r, int z, int, int k0, float (&v)[8]) const {
+        int py0, nh; wg_tap_rows(z, py0, nh);
+        const int o8 = k0 >> 3;
+        const int ri = (uniform || nh == 7) ? o8 / 7 : o8 / 6;
+        const int rw = o8 - ri * ((uniform || nh == 7) ? 7 : 6);
+        const bool ok = r.ok && ri < R && rw < nh;
+        const int py = py0 + (rw < nh ? rw : 0);
         const float* q = r.q + (int64_t)(ri < R ? ri : R - 1) * roi_stride;
-        // octets 0..5 are 8 contiguous pixels; octet 6 holds only p = 48: read pixels 41..48 and keep the last
+        // rows 0..5: the 8-float window starts at the row (its 8th float belongs to the next row and is dropped);
+        // row 6: read pixels 41..48 and shift by one, so the window never leaves the channel's 49 floats
         float t[8];
-        ld8_contig(q + (oc < 6 ? oc * 8 : 41), t);
-        v[0] = ok ? (oc < 6 ? t[0] : t[7]) : 0.f;
+        ld8_contig(q + (py < 6 ? py * 7 : 41), t);
 #pragma unroll
-        for (int j = 1; j < 8; ++j) v[j] = (ok && oc < 6) ? t[j] : 0.f;
+        for (int j = 0; j < 7; ++j) v[j] = ok ? (py < 6 ? t[j] : t[j + 1]) : 0.f;
+        v[7] = 0.f;
     }
 };
-// validity of the 8 pixels of octet oc (p = 8*oc + j) under tap t: bit j set when (py+dy, px+dx) is inside the 7x7 tile
-struct WgradMask { unsigned char m[9][7]; };
-constexpr WgradMask make_wgrad_mask() {
-    WgradMask w{};
-    for (int t = 0; t < 9; ++t)
-        for (int oc = 0; oc < 7; ++oc) {
-            unsigned b = 0;
-            for (int j = 0; j < 8; ++j) {
-                const int p = oc * 8 + j;
-                if (p >= 49) continue;
-                const int yy = p / 7 + t / 3 - 1, xx = p % 7 + t % 3 - 1;
-                if (yy >= 0 && yy < 7 && xx >= 0 && xx < 7) b |= 1u << j;
-            }
-            w.m[t][oc] = (unsigned char)b;
-        }
-    return w;
-}
-__constant__ WgradMask WGRAD_MASK = make_wgrad_mask();
-
-struct WgradB {        // B(n=ci, k') for tap z: x[r*roi_stride + ci*49 + shift(p, tap)]
-    const float* x; int64_t roi_stride; int Cin, R;
+struct WgradB {        // B(n=ci, k') for tap z: x[r*roi_stride + ci*49 + (py+dy)*7 + j + dx], 0 where j + dx leaves the row
+    const float* x; int64_t roi_stride; int Cin, R, uniform;
     static constexpr bool kfast = true;
     __device__ __forceinline__ float operator()(int z, int, int n, int k) const {
-        const int r = k / WG_PAD, p = k - r * WG_PAD;
-        if (n >= Cin || r >= R || p >= 49) return 0.f;
-        int py = p / 7, px = p - py * 7;
-        int yy = py + z / 3 - 1, xx = px + z % 3 - 1;
-        if ((unsigned)yy >= 7u || (unsigned)xx >= 7u) return 0.f;
-        return x[(int64_t)r * roi_stride + n * 49 + yy * 7 + xx];
+        int py0, nh; wg_tap_rows(z, py0, nh);
+        const int per = uniform ? 7 : nh;
+        const int o8 = k >> 3, j = k & 7, ri = o8 / per, rw = o8 - ri * per;
+        const int xx = j + z % 3 - 1;
+        if (n >= Cin || ri >= R || rw >= nh || j >= 7 || (unsigned)xx >= 7u) return 0.f;
+        return x[(int64_t)ri * roi_stride + n * 49 + (py0 + rw + z / 3 - 1) * 7 + xx];
     }
     struct Row { int n; bool ok; };
     __device__ __forceinline__ Row row(int, int n) const { return Row{n < Cin ? n : Cin - 1, n < Cin}; }
     template <bool FULLK>
     __device__ __forceinline__ void load8(const Row& r, int z, int, int k0, float (&v)[8]) const {
-        const int o8 = k0 >> 3, ri0 = o8 / 7, oc = o8 - ri0 * 7;
-        const bool ok = r.ok && ri0 < R;
+        int py0, nh; wg_tap_rows(z, py0, nh);
+        const int dyy = z / 3 - 1, dx = z % 3 - 1;
+        const int o8 = k0 >> 3;
+        const int ri0 = (uniform || nh == 7) ? o8 / 7 : o8 / 6;
+        const int rw = o8 - ri0 * ((uniform || nh == 7) ? 7 : 6);
+        const bool ok = r.ok && ri0 < R && rw < nh;
         const int ri = ri0 < R ? ri0 : R - 1;
-        const int off = (z / 3 - 1) * 7 + (z % 3 - 1);
-        // a valid pixel p reads source p + off, so the octet is ONE contiguous 8-float window starting at 8*oc + off;
-        // pixels whose source would fall outside the channel's 49 floats are exactly the masked ones, so the window
-        // may overhang into the neighbouring channel as long as it stays inside the tensor slice
-        const int64_t start = (int64_t)ri * roi_stride + r.n * 49 + oc * 8 + off;
+        const int py = py0 + (rw < nh ? rw : 0) + dyy;                   // source row, 0..6
+        // slots whose source column leaves the row are masked, so the 8-float window may start one float early
+        // (dx = -1) or overhang into the neighbouring channel as long as it stays inside the tensor slice
+        const int64_t start = (int64_t)ri * roi_stride + r.n * 49 + py * 7 + dx;
         const int64_t last = (int64_t)(R - 1) * roi_stride + (int64_t)Cin * 49 - 8;
-        const unsigned mask = ok ? WGRAD_MASK.m[z][oc] : 0u;
+        const unsigned mask = !ok ? 0u : (dx < 0 ? 0x7eu : (dx > 0 ? 0x3fu : 0x7fu));
         if (start >= 0 && start <= last) {
             ld8_contig(x + start, v);
 #pragma unroll
@@ -536,14 +536,35 @@ extern "C" int32_t arfe_conv3x3_bwd_weight(int32_t R, int32_t C, const float* x,
         int32_t zr = zero_buffers(z, st);
         if (zr) return zr;
     }
-    WgradA la{dy, dy_roi_stride, C, R};
-    WgradB lb{x, x_roi_stride, C, R};
-    const int Kp = R * WG_PAD;
-    int ksteps = cdiv(Kp, gemm_bk());
-    int splitk = pick_splitk(C, C, 9, ksteps);
+    // K per tap: R x (valid pixel rows) x 8 slots.  With the large-tile kernel every tap gets its own length and a share
+    // of the ~250 workgroups proportional to it; the other kernels walk 7 rows for every tap (`uniform`).
+    const int bk = gemm_bk();
+    const int steps7 = cdiv(R * 56, bk), steps6 = cdiv(R * 48, bk);
+    int sk_probe = 64;
+    const bool zvar = !gemm_use_f32() && plan_large_tile(C, C, 9, steps7, &sk_probe);
+    WgradA la{dy, dy_roi_stride, C, R, zvar ? 0 : 1};
+    WgradB lb{x, x_roi_stride, C, R, zvar ? 0 : 1};
     EpiPlain e = epi_plain(dwp, (int64_t)C * C, C);
     e.atomic = 1;
-    int32_t rc = launch_gemm_auto(C, C, Kp, 1, 9, splitk, la, lb, e, st);
+    int32_t rc;
+    if (zvar) {
+        GemmDims zv;
+        const int tiles = cdiv(C, XL_BM) * cdiv(C, XL_BN);
+        const int total_steps = 3 * steps7 + 6 * steps6;
+        const int budget = 252 / tiles > 9 ? 252 / tiles : 9;            // workgroups over the 9 taps (~ one per CU)
+        auto slices = [&](int st_z) {
+            int sp = (int)((int64_t)budget * st_z / total_steps);
+            const int cap = st_z / 8 > 1 ? st_z / 8 : 1;                  // at least 8 K-steps per slice
+            return sp < 1 ? 1 : (sp > cap ? cap : sp);
+        };
+        zv.zk_class = 0x38u;                                              // taps 3,4,5 (dy = 0): 7 pixel rows
+        zv.zk_steps0 = steps6; zv.zk_splits0 = slices(steps6);
+        zv.zk_steps1 = steps7; zv.zk_splits1 = slices(steps7);
+        rc = launch_gemm_auto(C, C, steps7 * bk, 1, 9, 64, la, lb, e, st, false, false, &zv);
+    } else {
+        const int Kp = R * 56;
+        rc = launch_gemm_auto(C, C, Kp, 1, 9, pick_splitk(C, C, 9, cdiv(Kp, bk)), la, lb, e, st);
+    }
     if (rc) return rc;
     hipLaunchKernelGGL(conv_dw_unpermute_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, dwp, dw, C);
     ARFE_CHECK_LAUNCH();
