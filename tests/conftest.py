@@ -34,3 +34,14 @@ def relerr(a, b):
         a = torch.zeros_like(b)
     a, b = a.detach().float().cpu(), b.detach().float().cpu()
     return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
+
+
+def relerr_l2(a, b):
+    """||a-b||_2 / ||b||_2.  Used next to `relerr` where tensors are large enough for ReLU kinks to matter: two fp32
+    implementations round a pre-activation of magnitude ~1e-7 to different signs about twice per million elements
+    (measured: 2 of 1 003 520 in each conv output of the mid-size head), which flips that element's mask and moves its
+    gradient by the full value - a max-norm outlier that is not an arithmetic error."""
+    if a is None:
+        a = torch.zeros_like(b)
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return (a - b).norm().item() / max(b.norm().item(), 1e-300)

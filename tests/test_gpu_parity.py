@@ -7,7 +7,7 @@ the north-star bound (TOL / TOL_GRAD) to catch indexing bugs; integer/index resu
 import pytest
 import torch
 
-from conftest import load_golden, relerr
+from conftest import load_golden, relerr, relerr_l2
 
 pytestmark = pytest.mark.gpu
 
@@ -298,6 +298,63 @@ def test_end_to_end_golden_through_plugin_surface(dev):
         assert relerr(v.grad, d['dhead.' + k]) <= TOL_GRAD, k
 
 
+def test_end_to_end_medium_matches_oracle(O, dev):
+    """A mid-size configuration between the golden toys and the bench (B=3, C=64, odd pyramid, R=330, RoI count not a
+    multiple of 4/32): other tile / split-K / per-tap-K planner branches than either; whole path against the oracle."""
+    import arfe_amd
+    g = torch.Generator().manual_seed(41)
+    B, C, fc = 3, 64, 96
+    sizes = ((100, 152), (50, 76), (25, 38), (13, 19), (7, 10))
+    neck = arfe_amd.build_neck(dict(type='WFPNDualSpatial', in_channels=C, num_levels=5)).to(dev)
+    roi_head = arfe_amd.build_head(dict(
+        type='StandardRoIHead',
+        bbox_roi_extractor=dict(type='SingleRoIExtractor', roi_layer=dict(type='RoIAlign', out_size=7, sample_num=0),
+                                out_channels=C, featmap_strides=[4, 8, 16, 32, 64]),
+        bbox_head=dict(type='MultiRoIsBBoxHead', in_channels=C, conv_out_channels=C, fc_out_channels=fc,
+                       roi_feat_size=7, num_classes=80))).to(dev)
+    pn = O.arfpn_params(C, 5, seed=5)
+    ph = O.rff_params(C, fc, 80, 7, seed=6)
+    for d in (pn, ph):
+        for k in d:
+            if k.endswith('bias'):
+                d[k] = torch.randn(d[k].shape, generator=g) * 0.1
+    neck.load_state_dict({k: v.clone() for k, v in pn.items()})
+    roi_head.bbox_head.load_state_dict({k: v.clone() for k, v in ph.items()})
+    xs_cpu = [torch.randn(B, C, h, w, generator=g) for h, w in sizes]
+    rois = O.synth_rois(B, 110, img_w=608, img_h=400, seed=9)
+    # reference on the CPU
+    pnr = {k: v.clone().requires_grad_(True) for k, v in pn.items()}
+    phr = {k: v.clone().requires_grad_(True) for k, v in ph.items()}
+    xr = [x.clone().requires_grad_(True) for x in xs_cpu]
+    feats_r = O.arfpn_forward(xr, pnr, refine_level=2)
+    cls_r, reg_r = O.rff_head(O.roi_extract3(list(feats_r), rois), phr)
+    cot_c, cot_r = torch.randn(cls_r.shape, generator=g), torch.randn(reg_r.shape, generator=g)
+    ((cls_r * cot_c).sum() + (reg_r * cot_r).sum()).backward()
+    # HIP path
+    xs = [x.clone().to(dev).requires_grad_(True) for x in xs_cpu]
+    res = roi_head._bbox_forward(neck(xs), rois.to(dev))
+    assert relerr(res['cls_score'], cls_r.detach()) <= TOL and relerr(res['bbox_pred'], reg_r.detach()) <= TOL
+    ((res['cls_score'] * cot_c.to(dev)).sum() + (res['bbox_pred'] * cot_r.to(dev)).sum()).backward()
+
+    # Gradients: at this size a couple of ReLU masks per million elements differ between any two fp32 implementations
+    # (see conftest.relerr_l2) and a flipped pixel perturbs everything downstream of it (all weights of its channel, and
+    # through the NonLocal attention every pixel of the pyramid gradient), so the bound is on the L2 error.
+    def close(a, b, what, tol=2e-3):
+        if b is None:       # the reference left no gradient (a level no RoI touched): ours must be exactly zero
+            assert a is None or float(a.abs().max()) == 0.0, what
+            return
+        assert relerr_l2(a, b) <= tol, (what, relerr_l2(a, b))
+
+    for i in range(5):
+        close(xs[i].grad, xr[i].grad, f'dx{i}')
+    for k, v in neck.named_parameters():
+        if k == 'refine.phi.conv.bias':        # mathematically zero gradient (softmax shift invariance): noise only
+            continue
+        close(v.grad, pnr[k].grad, k, 5e-3)
+    for k, v in roi_head.bbox_head.named_parameters():
+        close(v.grad, phr[k].grad, k, 5e-3)     # a flipped pixel feeds every weight / the bias of its channel
+
+
 def test_full_size_properties(Fn, O, dev):
     """BASELINE-size (B=2) properties that need no CPU reference run:
     scatter with zero gates is the identity; the path is linear in the upstream cotangent; empty RoI sets."""
@@ -468,7 +525,7 @@ def test_exact_fp32_mode_in_a_fresh_process():
     code = '''
 import sys, torch
 sys.path.insert(0, %r); sys.path.insert(0, %r + "/tests")
-from conftest import load_golden, relerr
+from conftest import load_golden, relerr, relerr_l2
 from arfe_amd import functional as Fn
 dev = torch.device("cuda:0")
 d = load_golden("rff_head_r40.npz")
