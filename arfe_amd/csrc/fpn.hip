@@ -464,7 +464,7 @@ __global__ __launch_bounds__(256) void fpn_scatter_bwd_dbsf_kernel(Levels lv, Le
 //   registers (they do not depend on the channel) and each wave handles IB_CG consecutive channels: per channel one 16-B
 //   read of g, 18 scalar weight loads (wave-uniform), 72 FMAs, the pooling term and one 16-B store.
 // =========================================================================================================
-constexpr int IB_CG = 4;   // channels whose reads are in flight together
+constexpr int IB_CG = 2;   // channels whose reads are in flight together
 constexpr int IB_NB = 4;   // such batches per wave (amortises the neighbourhood reads of the two maps)
 // Each index regime is its own instantiation so that only its paths are compiled in (all paths in one kernel made
 // 167 KB of code at 256 VGPRs): levels with an exact power-of-two ratio to the refine level use shifts only.
