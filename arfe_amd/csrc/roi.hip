@@ -400,14 +400,13 @@ __global__ __launch_bounds__(256) void roialign_fwd_sep_kernel(RoiLevels L, RoiS
             float v[RF_ROWS];
 #pragma unroll
             for (int j = 0; j < RF_ROWS; ++j) v[j] = f[(int64_t)(y + j < hext ? y + j : hext - 1) * W];
+            // rows past the window (y + j >= hext, still < RW_EXT) carry zero weight in the table: no branch per row
 #pragma unroll
             for (int j = 0; j < RF_ROWS; ++j) {
-                if (y + j < hext) {
-                    const float4_u wa = *reinterpret_cast<const float4_u*>(&wyT_s[y + j][0]);
-                    const float4_u wb = *reinterpret_cast<const float4_u*>(&wyT_s[y + j][4]);
-                    acc[0] += wa[0] * v[j]; acc[1] += wa[1] * v[j]; acc[2] += wa[2] * v[j]; acc[3] += wa[3] * v[j];
-                    acc[4] += wb[0] * v[j]; acc[5] += wb[1] * v[j]; acc[6] += wb[2] * v[j];
-                }
+                const float4_u wa = *reinterpret_cast<const float4_u*>(&wyT_s[y + j][0]);
+                const float4_u wb = *reinterpret_cast<const float4_u*>(&wyT_s[y + j][4]);
+                acc[0] += wa[0] * v[j]; acc[1] += wa[1] * v[j]; acc[2] += wa[2] * v[j]; acc[3] += wa[3] * v[j];
+                acc[4] += wb[0] * v[j]; acc[5] += wb[1] * v[j]; acc[6] += wb[2] * v[j];
             }
         }
 #pragma unroll
