@@ -226,7 +226,7 @@ extern "C" int32_t arfe_convmap3x3_fwd(int32_t B, int32_t C, int32_t H, int32_t 
     ARFE_CHECK_ARG(x && packed && y, ARFE_ERR_ARG, "convmap3x3_fwd: null pointer");
     const int HW = H * W;
     const float* wp = (const float*)packed;
-    LoadRowMajorK la{wp, 0, (int64_t)C * C, C, C, C};
+    LoadSplitK la{{wp, 0, (int64_t)C * C, C, C, C}};
     ConvMapB lb{x, (int64_t)C * HW, H, W, HW, C};
     EpiPlain e = epi_plain(y, (int64_t)C * HW, HW);
     e.bias_m = b;
@@ -240,7 +240,7 @@ extern "C" int32_t arfe_convmap3x3_bwd_data(int32_t B, int32_t C, int32_t H, int
     ARFE_CHECK_ARG(packed && dy && dx, ARFE_ERR_ARG, "convmap3x3_bwd_data: null pointer");
     const int HW = H * W;
     const float* wd = (const float*)packed + (size_t)9 * C * C;
-    LoadRowMajorK la{wd, 0, (int64_t)C * C, C, C, C};
+    LoadSplitK la{{wd, 0, (int64_t)C * C, C, C, C}};
     ConvMapB lb{dy, (int64_t)C * HW, H, W, HW, C};
     EpiPlain e = epi_plain(dx, (int64_t)C * HW, HW);
     return launch_gemm_auto(C, HW, C, 9, B, 1, la, lb, e, as_stream(stream), false, /*kb_inner=*/true);

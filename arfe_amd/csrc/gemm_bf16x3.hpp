@@ -42,6 +42,37 @@ __device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& 
     lo = __builtin_bit_cast(bf16x8, l);
 }
 
+// Pre-split operands: a matrix that is re-laid anyway before it is used (the conv weights) is stored as one 32-bit word
+// per element, bf16(x) in the upper half and bf16(x - bf16(x)) in the lower, i.e. exactly the pair split8 computes.
+// The loaders move the words like floats; staging is then two v_perm_b32 per element pair instead of a split.
+template <class L, class = void> struct is_presplit { static constexpr bool value = false; };
+template <class L> struct is_presplit<L, decltype((void)L::presplit)> { static constexpr bool value = L::presplit; };
+struct LoadSplitK : LoadRowMajorK {
+    static constexpr bool presplit = true;
+    typedef LoadRowMajorK Plain;
+};
+__device__ __forceinline__ unsigned presplit_word(float x) {
+    const __bf16 h = (__bf16)x;
+    const __bf16 l = (__bf16)(x - (float)h);
+    return ((unsigned)__builtin_bit_cast(unsigned short, h) << 16) | __builtin_bit_cast(unsigned short, l);
+}
+__device__ __forceinline__ void unpack8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+    u32x4 h, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned w0 = __float_as_uint(v[2 * j]), w1 = __float_as_uint(v[2 * j + 1]);
+        h[j] = __builtin_amdgcn_perm(w1, w0, 0x07060302u);
+        l[j] = __builtin_amdgcn_perm(w1, w0, 0x05040100u);
+    }
+    hi = __builtin_bit_cast(bf16x8, h);
+    lo = __builtin_bit_cast(bf16x8, l);
+}
+template <class L>
+__device__ __forceinline__ void stage8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+    if constexpr (is_presplit<L>::value) unpack8(v, hi, lo);
+    else split8(v, hi, lo);
+}
+
 template <class LA, class LB, class EPI>
 __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmDims d, LA la, LB lb, EPI epi) {
     // [operand image: 0 A_hi, 1 A_lo, 2 B_hi, 3 B_lo][row][k]
@@ -115,10 +146,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmDims d, LA la, 
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             bf16x8 hi, lo;
-            split8(ra[i], hi, lo);
+            stage8<LA>(ra[i], hi, lo);
             *reinterpret_cast<bf16x8*>(&lds[0][a_row[i]][8 * a_oct[i]]) = hi;
             *reinterpret_cast<bf16x8*>(&lds[1][a_row[i]][8 * a_oct[i]]) = lo;
-            split8(rb[i], hi, lo);
+            stage8<LB>(rb[i], hi, lo);
             *reinterpret_cast<bf16x8*>(&lds[2][b_row[i]][8 * b_oct[i]]) = hi;
             *reinterpret_cast<bf16x8*>(&lds[3][b_row[i]][8 * b_oct[i]]) = lo;
         }
@@ -477,7 +508,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_large_kernel(GemmDims d, L
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             bf16x8 hi, lo;
-            split8(ra[i], hi, lo);
+            stage8<LA>(ra[i], hi, lo);
             *reinterpret_cast<bf16x8*>(img(buf, 0) + a_row[i] * XB_LD + 8 * a_oct[i]) = hi;
             *reinterpret_cast<bf16x8*>(img(buf, 1) + a_row[i] * XB_LD + 8 * a_oct[i]) = lo;
         }
@@ -486,7 +517,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_large_kernel(GemmDims d, L
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             bf16x8 hi, lo;
-            split8(rb[i], hi, lo);
+            stage8<LB>(rb[i], hi, lo);
             *reinterpret_cast<bf16x8*>(img(buf, 2) + b_row[i] * XB_LD + 8 * b_oct[i]) = hi;
             *reinterpret_cast<bf16x8*>(img(buf, 3) + b_row[i] * XB_LD + 8 * b_oct[i]) = lo;
         }
@@ -669,14 +700,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_n224_kernel(GemmDims d, LA
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             bf16x8 hi, lo;
-            split8(ra[i], hi, lo);
+            stage8<LA>(ra[i], hi, lo);
             *reinterpret_cast<bf16x8*>(img_a(buf, 0) + a_row[i] * XB_LD + 8 * a_oct[i]) = hi;
             *reinterpret_cast<bf16x8*>(img_a(buf, 1) + a_row[i] * XB_LD + 8 * a_oct[i]) = lo;
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             bf16x8 hi, lo;
-            split8(rb[i], hi, lo);
+            stage8<LB>(rb[i], hi, lo);
             if (b_ok[i]) {
                 *reinterpret_cast<bf16x8*>(img_b(buf, 0) + b_row[i] * XB_LD + 8 * b_oct[i]) = hi;
                 *reinterpret_cast<bf16x8*>(img_b(buf, 1) + b_row[i] * XB_LD + 8 * b_oct[i]) = lo;
@@ -772,9 +803,20 @@ template <class LA, class LB, class EPI>
 static inline int32_t launch_gemm_auto(int M, int N, int K, int kb_count, int batch, int splitk, LA la, LB lb, EPI epi,
                                        hipStream_t stream, bool exact = false, bool kb_inner = false,
                                        const GemmDims* zvar = nullptr) {
-    if (gemm_use_f32()) return launch_gemm(M, N, K, kb_count, batch, splitk, la, lb, epi, stream, kb_inner);
+    if constexpr (is_presplit<LA>::value) {
+        // in fp32 mode the re-laid matrix holds plain floats (see conv_w_permute_kernel)
+        if (gemm_use_f32())
+            return launch_gemm(M, N, K, kb_count, batch, splitk, static_cast<const typename LA::Plain&>(la), lb, epi, stream,
+                               kb_inner);
+        if (exact) {
+            set_error("gemm: pre-split operands are not available on the bf16x6 path");
+            return ARFE_ERR_ARG;
+        }
+    } else {
+        if (gemm_use_f32()) return launch_gemm(M, N, K, kb_count, batch, splitk, la, lb, epi, stream, kb_inner);
+    }
     if (M <= 0 || N <= 0 || batch <= 0) return ARFE_OK;
-    if (exact) {        // fp32-grade products from six bf16 MFMAs (see gemm_bf16x6_kernel)
+    if constexpr (!is_presplit<LA>::value) if (exact) {        // fp32-grade products from six bf16 MFMAs (see gemm_bf16x6_kernel)
         GemmDims d6;
         d6.M = M; d6.N = N; d6.K = K; d6.kb_count = kb_count < 1 ? 1 : kb_count;
         d6.kb_inner = kb_inner ? 1 : 0;

@@ -156,14 +156,22 @@ struct WgradB {        // B(n=ci, k') for tap z: x[r*roi_stride + ci*49 + (py+dy
 };
 
 // w [Cout,Cin,3,3] -> wp[tap][co][ci] (fwd) or wd[tap][ci][co] = w[co][ci][8-tap] (transposed + flipped, dgrad)
-__global__ void conv_w_permute_kernel(const float* __restrict__ w, float* __restrict__ wp, float* __restrict__ wd, int C) {
+// presplit: the elements are stored as (bf16 hi << 16 | bf16 lo) words for LoadSplitK (bf16x3 mode), else as floats
+__global__ void conv_w_permute_kernel(const float* __restrict__ w, float* __restrict__ wp, float* __restrict__ wd, int C,
+                                      int presplit) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     int total = C * C * 9;
     if (i >= total) return;
     int tap = i / (C * C), rem = i - tap * C * C;
     int a = rem / C, b = rem - a * C;
-    wp[i] = w[((int64_t)a * C + b) * 9 + tap];           // wp[tap][co=a][ci=b]
-    wd[i] = w[((int64_t)b * C + a) * 9 + (8 - tap)];     // wd[tap][ci=a][co=b]
+    float f = w[((int64_t)a * C + b) * 9 + tap];           // wp[tap][co=a][ci=b]
+    float g = w[((int64_t)b * C + a) * 9 + (8 - tap)];     // wd[tap][ci=a][co=b]
+    if (presplit) {
+        f = __uint_as_float(presplit_word(f));
+        g = __uint_as_float(presplit_word(g));
+    }
+    wp[i] = f;
+    wd[i] = g;
 }
 // dwp[tap][co][ci] -> dw[co][ci][tap]
 __global__ void conv_dw_unpermute_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int C) {
@@ -483,7 +491,8 @@ extern "C" int32_t arfe_conv3x3_pack_weights(int32_t C, const float* w, void* pa
     float* wp = (float*)packed;
     float* wd = wp + (size_t)9 * C * C;
     int total = 9 * C * C;
-    hipLaunchKernelGGL(conv_w_permute_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), w, wp, wd, C);
+    hipLaunchKernelGGL(conv_w_permute_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), w, wp, wd, C,
+                       gemm_use_f32() ? 0 : 1);
     ARFE_CHECK_LAUNCH();
     return ARFE_OK;
 }
@@ -494,7 +503,7 @@ extern "C" int32_t arfe_conv3x3_fwd(int32_t R, int32_t C, const float* x, int64_
     if (R == 0) return ARFE_OK;
     ARFE_CHECK_ARG(x && packed && y, ARFE_ERR_ARG, "conv3x3_fwd: null pointer");
     const float* wp = (const float*)packed;
-    LoadRowMajorK la{wp, 0, (int64_t)C * C, C, C, C};     // A(m=co,k=ci) for tap kb
+    LoadSplitK la{{wp, 0, (int64_t)C * C, C, C, C}};     // A(m=co,k=ci) for tap kb, pre-split words
     ConvGatherB lb{x, x_roi_stride, R * 49, C, conv_zeros()};
     ARFE_CHECK_ARG(lb.zeros, ARFE_ERR_LAUNCH, "conv3x3: cannot allocate the padding block");
     EpiConv e{y, y_roi_stride, b, relu, nullptr, 0};
@@ -508,7 +517,7 @@ extern "C" int32_t arfe_conv3x3_bwd_data(int32_t R, int32_t C, const void* packe
     if (R == 0) return ARFE_OK;
     ARFE_CHECK_ARG(packed && dy && dx, ARFE_ERR_ARG, "conv3x3_bwd_data: null pointer");
     const float* wd = (const float*)packed + (size_t)9 * C * C;
-    LoadRowMajorK la{wd, 0, (int64_t)C * C, C, C, C};      // A(m=ci,k=co) = w[co][ci][8-tap]
+    LoadSplitK la{{wd, 0, (int64_t)C * C, C, C, C}};      // A(m=ci,k=co) = w[co][ci][8-tap], pre-split words
     ConvGatherB lb{dy, dy_roi_stride, R * 49, C, conv_zeros()};
     ARFE_CHECK_ARG(lb.zeros, ARFE_ERR_LAUNCH, "conv3x3: cannot allocate the padding block");
     EpiConv e{dx, dx_roi_stride, nullptr, 0, dx_mask, dx_mask_roi_stride};

@@ -204,7 +204,7 @@ def main():
             "roofline": {"bound": "mfma",
                          "kernel": ("gemm_f32_kernel" if f32_mode else
                                     "gemm_bf16x3_n224_kernel (256x224 tile) / gemm_bf16x3_large_kernel (256x256)") +
-                                   "<LoadRowMajorK,ConvGatherB,EpiConv> (3x3 conv 256->256 on [R,256,7,7], fwd + data-grad)",
+                                   "<LoadSplitK,ConvGatherB,EpiConv> (3x3 conv 256->256 on [R,256,7,7], fwd + data-grad)",
                          "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(ach / peak, 4),
                          "traffic": None if f32_mode else pmc_traffic(("gemm_bf16x3_", "ConvGatherB")),
