@@ -73,7 +73,59 @@ int32_t check_pyramid(const arfe_pyramid_t* p) {
     return ARFE_OK;
 }
 
+// fp16 storage <-> fp32 compute (the fp16 mode of the reference, mmdet/core/fp16): 8 elements per thread, round to
+// nearest even on the way down.
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float float8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void cast_h2f_kernel(const _Float16* __restrict__ src, float* __restrict__ dst, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * 256 * 8;
+    const bool aligned = (((uintptr_t)src & 15) | ((uintptr_t)dst & 31)) == 0;
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8; i < n; i += stride) {
+        if (aligned && i + 7 < n) {
+            const half8 h = *reinterpret_cast<const half8*>(src + i);
+            *reinterpret_cast<float8*>(dst + i) = __builtin_convertvector(h, float8);
+        } else {
+            for (int e = 0; e < 8 && i + e < n; ++e) dst[i + e] = (float)src[i + e];
+        }
+    }
+}
+__global__ __launch_bounds__(256) void cast_f2h_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * 256 * 8;
+    const bool aligned = (((uintptr_t)src & 31) | ((uintptr_t)dst & 15)) == 0;
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8; i < n; i += stride) {
+        if (aligned && i + 7 < n) {
+            const float8 f = *reinterpret_cast<const float8*>(src + i);
+            *reinterpret_cast<half8*>(dst + i) = __builtin_convertvector(f, half8);
+        } else {
+            for (int e = 0; e < 8 && i + e < n; ++e) dst[i + e] = (_Float16)src[i + e];
+        }
+    }
+}
+
 }  // namespace arfe
+
+extern "C" int32_t arfe_cast_f16_to_f32(int64_t n, const void* src, float* dst, void* stream) {
+    using namespace arfe;
+    ARFE_CHECK_ARG(n >= 0, ARFE_ERR_ARG, "cast_f16_to_f32: n=%lld", (long long)n);
+    if (n == 0) return ARFE_OK;
+    ARFE_CHECK_ARG(src && dst, ARFE_ERR_ARG, "cast_f16_to_f32: null pointer");
+    int64_t g = cdiv64(n, 256 * 8 * 2);
+    g = g < 1 ? 1 : (g > 8192 ? 8192 : g);
+    hipLaunchKernelGGL(cast_h2f_kernel, dim3((unsigned)g), dim3(256), 0, as_stream(stream), (const _Float16*)src, dst, n);
+    ARFE_CHECK_LAUNCH();
+    return ARFE_OK;
+}
+extern "C" int32_t arfe_cast_f32_to_f16(int64_t n, const float* src, void* dst, void* stream) {
+    using namespace arfe;
+    ARFE_CHECK_ARG(n >= 0, ARFE_ERR_ARG, "cast_f32_to_f16: n=%lld", (long long)n);
+    if (n == 0) return ARFE_OK;
+    ARFE_CHECK_ARG(src && dst, ARFE_ERR_ARG, "cast_f32_to_f16: null pointer");
+    int64_t g = cdiv64(n, 256 * 8 * 2);
+    g = g < 1 ? 1 : (g > 8192 ? 8192 : g);
+    hipLaunchKernelGGL(cast_f2h_kernel, dim3((unsigned)g), dim3(256), 0, as_stream(stream), src, (_Float16*)dst, n);
+    ARFE_CHECK_LAUNCH();
+    return ARFE_OK;
+}
 
 extern "C" const char* arfe_last_error(void) { return arfe::g_err; }
 extern "C" int32_t arfe_abi_version(void) { return ARFE_ABI_VERSION; }

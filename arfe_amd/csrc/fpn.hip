@@ -780,7 +780,9 @@ __global__ __launch_bounds__(256) void fpn_gate_wgrad_mfma_kernel(Levels lv, Til
     int nst = (hw - px_begin + GW_PX - 1) / GW_PX;
     if (nst > GW_STAGES) nst = GW_STAGES;
 
-    for (int i = tid; i < 32 * GW_LD; i += 256) (&Ds[0][0])[i] = 0.f;       // rows 18..31 stay zero
+    // rows GM_M..31 of the MFMA operand stay zero; rows below are rewritten by every stage (zeroing them here too would
+    // race with the first stage's writes: there is no barrier in between)
+    for (int i = tid; i < (32 - GM_M) * GW_LD; i += 256) (&Ds[GM_M][0])[i] = 0.f;
     f32x16_t acc[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)

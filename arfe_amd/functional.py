@@ -616,3 +616,69 @@ def nearest_add(lat, top):
 
 def subsample2(x):
     return Subsample2Function.apply(x)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# fp16 mode: half storage at the module boundary, fp32 inside the library
+# ---------------------------------------------------------------------------------------------------------
+def _cast_op(x, to_half):
+    x = x.contiguous()
+    if not x.is_cuda:
+        raise hip.ArfeHipError(f"the HIP cast kernels need a GPU tensor, got {x.device}")
+    want = torch.float32 if to_half else torch.float16
+    if x.dtype != want:
+        raise hip.ArfeHipError(f"cast expects {want}, got {x.dtype}")
+    out = torch.empty(x.shape, dtype=torch.float16 if to_half else torch.float32, device=x.device)
+    fn = hip.lib().arfe_cast_f32_to_f16 if to_half else hip.lib().arfe_cast_f16_to_f32
+    check(fn(x.numel(), ptr(x), ptr(out), stream()), "arfe_cast")
+    return out
+
+
+class CastFunction(torch.autograd.Function):
+    """Tensor.to(half) / Tensor.to(float) of cast_tensor_type (mmdet/core/fp16/utils.py:7-23); the gradient takes the
+    inverse conversion, as autograd's does."""
+
+    @staticmethod
+    def forward(ctx, x, to_half):
+        ctx.to_half = to_half
+        return _cast_op(x, to_half)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _cast_op(g, not ctx.to_half), None
+
+
+def to_f32(t):
+    """half -> float through the library (float tensors pass through)."""
+    if t is None or t.dtype == torch.float32:
+        return t
+    return CastFunction.apply(t, False)
+
+
+def to_f16(t):
+    if t is None or t.dtype == torch.float16:
+        return t
+    return CastFunction.apply(t, True)
+
+
+def storage_dtype(tensors, params, what):
+    """The dtype a reference module would compute in: inputs and parameters must agree (fp32, or half after
+    wrap_fp16_model); a mismatch is the RuntimeError torch's conv / linear raise in the reference."""
+    dts = {t.dtype for t in list(tensors) + list(params) if t is not None}
+    if len(dts) != 1 or next(iter(dts)) not in (torch.float32, torch.float16):
+        raise RuntimeError(f"{what}: input and parameter dtypes should be the same fp32 or fp16 type, got "
+                           f"{sorted(str(d) for d in dts)}")
+    return next(iter(dts))
+
+
+def f32_boundary(tensors, params, what):
+    """-> (tensors, params, finish): fp32 views of a module's activations and parameters for the library, and
+    `finish(out)` returning the outputs in the module's storage dtype (half in fp16 mode)."""
+    dt = storage_dtype(tensors, params, what)
+    if dt == torch.float32:
+        return list(tensors), list(params), lambda out: out
+    def finish(out):
+        if isinstance(out, (tuple, list)):
+            return type(out)(to_f16(o) for o in out)
+        return to_f16(out)
+    return [to_f32(t) for t in tensors], [to_f32(p) for p in params], finish

@@ -74,6 +74,8 @@ SIGNATURES = {
     "arfe_nearest_add_fwd": (_i32, [_i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp]),
     "arfe_nearest_add_bwd": (_i32, [_i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp]),
     "arfe_subsample2": (_i32, [_i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
+    "arfe_cast_f16_to_f32": (_i32, [_i64, _vp, _vp, _vp]),
+    "arfe_cast_f32_to_f16": (_i32, [_i64, _vp, _vp, _vp]),
 }
 
 _lib = None

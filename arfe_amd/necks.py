@@ -4,6 +4,7 @@ import torch.nn as nn
 
 from . import functional as Fn
 from .cnn import ConvModule, xavier_init
+from .fp16 import auto_fp16
 from .non_local import NonLocal2D
 from .registry import NECKS
 
@@ -38,8 +39,11 @@ class WFPNDualSpatial(nn.Module):
         b1 = [m.conv.bias for m in self.reduce_convs]
         w2 = [m.conv.weight for m in self.reduce_convs2]
         b2 = [m.conv.bias for m in self.reduce_convs2]
-        return tuple(Fn.arfpn(list(inputs), w1, b1, w2, b2, *self.refine.hip_params(),
-                              refine_level=self.refine_level))
+        # fp16 mode (wrap_fp16_model): half storage, fp32 inside the library
+        n = self.num_levels
+        xs, p, finish = Fn.f32_boundary(inputs, w1 + b1 + w2 + b2 + list(self.refine.hip_params()), 'WFPNDualSpatial')
+        return finish(tuple(Fn.arfpn(xs, p[:n], p[n:2 * n], p[2 * n:3 * n], p[3 * n:4 * n], *p[4 * n:],
+                                     refine_level=self.refine_level)))
 
 
 @NECKS.register_module()
@@ -88,14 +92,16 @@ class FPN(nn.Module):
             if isinstance(m, nn.Conv2d):
                 xavier_init(m, distribution='uniform')
 
+    @auto_fp16()
     def forward(self, inputs):
         assert len(inputs) == len(self.in_channels)
-        laterals = [Fn.conv1x1(inputs[i + self.start_level], m.conv.weight, m.conv.bias)
-                    for i, m in enumerate(self.lateral_convs)]
-        used = len(laterals)
+        used = len(self.lateral_convs)
+        params = [t for m in list(self.lateral_convs) + list(self.fpn_convs) for t in (m.conv.weight, m.conv.bias)]
+        xs, p, finish = Fn.f32_boundary(inputs, params, 'FPN')
+        laterals = [Fn.conv1x1(xs[i + self.start_level], p[2 * i], p[2 * i + 1]) for i in range(used)]
         for i in range(used - 1, 0, -1):
             laterals[i - 1] = Fn.nearest_add(laterals[i - 1], laterals[i])
-        outs = [Fn.convmap3x3(laterals[i], self.fpn_convs[i].conv.weight, self.fpn_convs[i].conv.bias) for i in range(used)]
+        outs = [Fn.convmap3x3(laterals[i], p[2 * (used + i)], p[2 * (used + i) + 1]) for i in range(used)]
         for _ in range(self.num_outs - used):
             outs.append(Fn.subsample2(outs[-1]))
-        return tuple(outs)
+        return finish(tuple(outs))

@@ -58,4 +58,5 @@ class NonLocal2D(nn.Module):
                 self.conv_out.conv.weight.view(c, c), self.conv_out.conv.bias)
 
     def forward(self, x):
-        return _NonLocalFunction.apply(x, *self.hip_params())
+        (x,), p, finish = Fn.f32_boundary([x], self.hip_params(), 'NonLocal2D')
+        return finish(_NonLocalFunction.apply(x, *p))

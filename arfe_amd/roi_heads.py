@@ -8,6 +8,7 @@ from torch.nn.modules.utils import _pair
 
 from . import functional as Fn
 from .cnn import ConvModule, xavier_init
+from .fp16 import force_fp32
 from .registry import HEADS, ROI_EXTRACTORS, build_head, build_roi_extractor
 from .roi_align import RoIAlign
 
@@ -46,13 +47,19 @@ class SingleRoIExtractor(nn.Module):
     def map_roi_levels(self, rois, num_levels):
         return Fn.map_roi_levels_op(rois.contiguous(), num_levels, self.finest_scale)
 
+    @force_fp32(apply_to=('feats', ), out_fp16=True)
     def forward(self, feats, rois, roi_scale_factor=None, lvl=None, replace_rois=None):
         if roi_scale_factor is not None or lvl is not None or replace_rois is not None:
             raise NotImplementedError("roi_scale_factor / lvl / replace_rois are unused by the AR-RFF path")
-        return self.extract_sets(feats, [rois])
+        return self._extract(feats, [rois])
 
+    @force_fp32(apply_to=('feats', ), out_fp16=True)
     def extract_sets(self, feats, roi_sets):
-        """RoIAlign of several RoI sets into one channel-concatenated tensor (set s -> channels [s*C,(s+1)*C))."""
+        """RoIAlign of several RoI sets into one channel-concatenated tensor (set s -> channels [s*C,(s+1)*C));
+        fp32 inside and half out in fp16 mode, like `forward` (single_level.py:109)."""
+        return self._extract(feats, roi_sets)
+
+    def _extract(self, feats, roi_sets):
         layer = self.roi_layers[0]
         feats = list(feats)[:self.num_inputs]
         return Fn.roi_extract(feats, [r.float() for r in roi_sets], self.featmap_strides[:len(feats)], self.finest_scale,
@@ -138,11 +145,14 @@ class MultiBBoxHead(BBoxHead):
                 xavier_init(m, distribution='uniform')
 
     def forward(self, x):
-        return Fn.rff_head(x, self.wh_conv.conv.weight, self.wh_conv.conv.bias, self.hh_conv.conv.weight,
-                           self.hh_conv.conv.bias, self.final_conv.conv.weight, self.final_conv.conv.bias,
-                           self.shared_fcs[0].weight, self.shared_fcs[0].bias, self.shared_fcs[1].weight,
-                           self.shared_fcs[1].bias, self.fc_cls.weight, self.fc_cls.bias, self.fc_reg.weight,
-                           self.fc_reg.bias)
+        # no @auto_fp16 on this forward in the reference (multirois_bbox_head.py:165): in fp16 mode x arrives as half
+        # from the extractor (out_fp16) and meets half parameters
+        params = [self.wh_conv.conv.weight, self.wh_conv.conv.bias, self.hh_conv.conv.weight, self.hh_conv.conv.bias,
+                  self.final_conv.conv.weight, self.final_conv.conv.bias, self.shared_fcs[0].weight,
+                  self.shared_fcs[0].bias, self.shared_fcs[1].weight, self.shared_fcs[1].bias, self.fc_cls.weight,
+                  self.fc_cls.bias, self.fc_reg.weight, self.fc_reg.bias]
+        (x,), p, finish = Fn.f32_boundary([x], params, 'MultiBBoxHead')
+        return finish(Fn.rff_head(x, *p))
 
 
 @HEADS.register_module()

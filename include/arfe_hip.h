@@ -220,6 +220,13 @@ int32_t arfe_nearest_add_bwd(int32_t B, int32_t C, int32_t h, int32_t w, float* 
 int32_t arfe_subsample2(int32_t B, int32_t C, int32_t H, int32_t W, const float* in, float* out, int32_t backward,
                         void* stream);
 
+/* ---- fp16 mode: mmdet/core/fp16/utils.py:7-23 cast_tensor_type ------------------------------------
+ * The reference's fp16 mode (hooks.py:86-105 wrap_fp16_model, decorators.py:8-63 auto_fp16, :66-123 force_fp32) stores
+ * parameters and activations as IEEE half; this library computes in fp32, so the module boundary converts with these
+ * two kernels (round to nearest even, inf/nan preserved, like Tensor.to).  src/dst: n contiguous elements. */
+int32_t arfe_cast_f16_to_f32(int64_t n, const void* src, float* dst, void* stream);
+int32_t arfe_cast_f32_to_f16(int64_t n, const float* src, void* dst, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -310,6 +310,41 @@ def rff_head(x, p, return_parts=False):
 
 
 # ----------------------------------------------------------------------------------------
+# fp16 mode
+# ----------------------------------------------------------------------------------------
+class _HalfStore(torch.autograd.Function):
+    """x.half() as a storage step: the value is rounded to IEEE half (kept in an fp32 tensor here) and so is the
+    gradient that flows back through it (cast_tensor_type, mmdet/core/fp16/utils.py:7-23, is Tensor.to)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.half().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.half().float()
+
+
+def half_store(t):
+    return _HalfStore.apply(t)
+
+
+def fp16_mode_forward(xs, p_fpn, p_neck, p_head, rois, num_outs=5, refine_level=2):
+    """The path after wrap_fp16_model (mmdet/core/fp16/hooks.py:86-105): parameters hold half values (pass them as
+    the fp32 images of those halves), FPN.forward casts its inputs to half (@auto_fp16, fpn.py:166), the neck and the
+    head run on half tensors, the RoI extractor computes in fp32 and returns half (@force_fp32(feats), out_fp16,
+    single_level.py:109).  This restatement computes every module in fp32 and rounds to half exactly where a tensor
+    is STORED between modules - the accuracy contract of the HIP fp16 mode (the reference additionally rounds inside
+    its half kernels; tests bound that difference against fixtures made by the reference itself).
+    -> (pyramid, feats, bbox_feats, cls, reg), fp32 tensors holding half-representable values."""
+    pyr = [half_store(t) for t in fpn_forward([half_store(x) for x in xs], p_fpn, num_outs)]
+    feats = [half_store(t) for t in arfpn_forward(pyr, p_neck, refine_level)]
+    bbox_feats = half_store(roi_extract3(feats, rois))
+    cls, reg = rff_head(bbox_feats, p_head)
+    return pyr, feats, bbox_feats, half_store(cls), half_store(reg)
+
+
+# ----------------------------------------------------------------------------------------
 # parameter construction (same shapes/names/init as the reference modules, SURVEY §3.3, §8b)
 # ----------------------------------------------------------------------------------------
 

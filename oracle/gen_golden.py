@@ -261,6 +261,69 @@ def fpn_case(ns, name, in_channels, out_channels, sizes, batch, num_outs, seed):
     print('wrote', name)
 
 
+def wrap_fp16(model):
+    """wrap_fp16_model of mmdet/core/fp16/hooks.py:86-105 restated (that file imports mmcv.runner and cannot be loaded);
+    there are no norm layers on the path, so patch_norm_fp32 has nothing to patch."""
+    model.half()
+    for m in model.modules():
+        if hasattr(m, 'fp16_enabled'):
+            m.fp16_enabled = True
+
+
+def fp16_case(ns):
+    """The path in the reference's fp16 mode, run by the reference itself in half on the CPU: FPN (@auto_fp16, fpn.py:166)
+    -> WFPNDualSpatial -> SingleRoIExtractor (@force_fp32(feats), out_fp16, single_level.py:109) x 3 RoI sets ->
+    MultiRoIsBBoxHead, forward and backward.  Parameters are stored as the half values the modules hold."""
+    gen = torch.Generator().manual_seed(91)
+    torch.manual_seed(91)
+    C = 8
+    in_ch = (4, 6, 8, 10)
+    sizes = ((40, 64), (20, 32), (10, 16), (5, 8))
+    fpn = ns.FPN(list(in_ch), C, 5)
+    fpn.init_weights()
+    randomise(fpn, gen)
+    neck = ns.WFPNDualSpatial(C, 5)
+    neck.init_weights()
+    randomise(neck, gen)
+    with torch.no_grad():                      # conv_out is zero-initialised: give the NonLocal branch a visible effect
+        neck.refine.conv_out.conv.weight.copy_(torch.randn(C, C, 1, 1, generator=gen) * 0.3)
+    head = ns.MultiRoIsBBoxHead(in_channels=C, conv_out_channels=C, fc_out_channels=24, roi_feat_size=7, num_classes=80)
+    head.init_weights()
+    randomise(head, gen)
+    ext = ns.SingleRoIExtractor(dict(type='RoIAlign', out_size=7, sample_num=0), C, [4, 8, 16, 32, 64])
+    for m in (fpn, neck, head, ext):
+        wrap_fp16(m)
+    xs = [torch.randn(2, c, h, w, generator=gen, requires_grad=True) for c, (h, w) in zip(in_ch, sizes)]
+    n = 24
+    x1 = torch.rand(n, generator=gen) * 180
+    y1 = torch.rand(n, generator=gen) * 100
+    w = torch.exp(torch.rand(n, generator=gen) * 3.5 + 1.5)
+    h = torch.exp(torch.rand(n, generator=gen) * 3.5 + 1.5)
+    rois = torch.stack([(torch.arange(n) // 12).float(), x1, y1, x1 + w, y1 + h], 1)
+    pyr = fpn(xs)
+    feats = neck(pyr)
+    lh_rois, lw_rois = ns.get_adaptive_scale_rois(rois, 1)
+    bbox_feats = torch.cat([ext(feats, rois), ext(feats, lw_rois), ext(feats, lh_rois)], dim=1)
+    cls, reg = head(bbox_feats)
+    assert all(t.dtype == torch.float16 for t in (*pyr, *feats, bbox_feats, cls, reg))
+    c1 = torch.randn(cls.shape, generator=gen).half()
+    c2 = torch.randn(reg.shape, generator=gen).half()
+    ((cls * c1).sum() + (reg * c2).sum()).backward()
+    d = dict(rois=rois, cls=cls, reg=reg, cot_cls=c1, cot_reg=c2, bbox_feats=bbox_feats)
+    for i in range(4):
+        d[f'x{i}'] = xs[i]
+        d[f'dx{i}'] = xs[i].grad
+    for i in range(5):
+        d[f'pyr{i}'] = pyr[i]
+        d[f'feat{i}'] = feats[i]
+    for tag, mod in (('fpn.', fpn), ('neck.', neck), ('head.', head)):
+        for n_, p in mod.named_parameters():
+            d[tag + n_] = p
+            d['d' + tag + n_] = p.grad if p.grad is not None else torch.zeros_like(p)
+    np.savez_compressed(os.path.join(OUT, 'fp16_e2e_small.npz'), **npd(d))
+    print('fp16 e2e ok')
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ns = load_reference()
@@ -279,6 +342,7 @@ def main():
     head_case(ns, 'rff_head_r40.npz', 8, 24, 40, seed=7)
     e2e_case(ns)
     fpn_cases(ns)
+    fp16_case(ns)
 
 
 def fpn_cases(ns):
@@ -290,5 +354,8 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'fpn':     # only the base-FPN fixtures (keeps the others byte-identical)
         os.makedirs(OUT, exist_ok=True)
         fpn_cases(load_reference())
+    elif len(sys.argv) > 1 and sys.argv[1] == 'fp16':  # only the fp16-mode fixture
+        os.makedirs(OUT, exist_ok=True)
+        fp16_case(load_reference())
     else:
         main()

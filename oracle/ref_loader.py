@@ -158,6 +158,13 @@ def load_reference():
     """Returns a namespace with the reference classes/functions of the hot path."""
     assert reference_available(), f"{REF_ROOT} not present (expected on the GPU box)"
     _install_stubs()
+    # the reference's own fp16 decorators (pass-through unless a module's fp16_enabled is set); hooks.py, which holds
+    # wrap_fp16_model, imports mmcv.runner and cannot be loaded - gen_golden restates its 5 lines
+    _mod('mmdet.core.fp16')
+    _load('mmdet.core.fp16.utils', 'mmdet/core/fp16/utils.py')
+    deco = _load('mmdet.core.fp16.decorators', 'mmdet/core/fp16/decorators.py')
+    sys.modules['mmdet.core'].auto_fp16 = deco.auto_fp16
+    sys.modules['mmdet.core'].force_fp32 = deco.force_fp32
     nl = _load('mmdet.ops.non_local', 'mmdet/ops/non_local.py')
     sys.modules['mmdet.ops'].NonLocal2D = nl.NonLocal2D
     neck = _load('mmdet.models.necks.wfpn_dual_spatial', 'mmdet/models/necks/wfpn_dual_spatial.py')

@@ -150,3 +150,63 @@ def test_reference_configs_load_unchanged():
     libra = arfe_amd.Config.fromfile(os.path.join(REF, 'libra_rcnn', 'libra_faster_rcnn_r50_fpn_1x_coco.py'))
     wf = [n for n in libra.model.neck if n['type'] == 'WFPNDualSpatial'][0]
     assert arfe_amd.build_neck(wf).refine_level == wf.get('refine_level', 2)
+
+
+def test_fp16_decorators_and_wrap_mirror_the_reference():
+    """mmdet/core/fp16: decorators.py:8-123, utils.py:7-23, hooks.py:86-127 (host logic, CPU tensors)."""
+    import torch.nn as nn
+    from arfe_amd import auto_fp16, cast_tensor_type, force_fp32, wrap_fp16_model
+
+    class M(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.fp16_enabled = False
+            self.lin = nn.Linear(2, 2)
+            self.bn = nn.BatchNorm1d(2)
+
+        @auto_fp16(apply_to=('x', ))
+        def f(self, x, y):
+            return x, y
+
+        @auto_fp16(out_fp32=True)
+        def g(self, x, y=None):
+            return [x, dict(y=y)]
+
+        @force_fp32(apply_to=('feats', ), out_fp16=True)
+        def h(self, feats, rois):
+            return feats[0] * 2, rois
+
+    m = M()
+    a, b = torch.ones(2), torch.ones(2)
+    x, y = m.f(a, b)
+    assert x.dtype == torch.float32 and y.dtype == torch.float32            # pass-through until enabled
+    wrap_fp16_model(m)
+    assert m.fp16_enabled and m.lin.weight.dtype == torch.float16
+    assert m.bn.weight.dtype == torch.float32                               # patch_norm_fp32
+    x, y = m.f(a, b)
+    assert x.dtype == torch.float16 and y.dtype == torch.float32            # apply_to
+    out = m.g(a, y=b)
+    assert out[0].dtype == torch.float32 and out[1]['y'].dtype == torch.float32     # cast in, out_fp32 back
+    o, r = m.h((a.half(), b.half()), b)
+    assert o.dtype == torch.float16 and r.dtype == torch.float16            # out_fp16 converts every output tensor
+    # like the reference's cast_tensor_type, src_type is not consulted: every tensor in the structure is converted
+    c = cast_tensor_type({'i': torch.ones(2, dtype=torch.int64), 's': 'txt', 'n': 3}, torch.float, torch.half)
+    assert c['i'].dtype == torch.float16 and c['s'] == 'txt' and c['n'] == 3
+
+    class NotAModule:
+        @auto_fp16()
+        def f(self, x):
+            return x
+    with pytest.raises(TypeError):
+        NotAModule().f(a)
+
+
+def test_fp16_mode_mismatch_and_cpu_refusal():
+    import arfe_amd
+    neck = arfe_amd.build_neck(dict(type='WFPNDualSpatial', in_channels=4, num_levels=5))
+    arfe_amd.wrap_fp16_model(neck)
+    xs = [torch.randn(1, 4, h, w) for h, w in ((8, 8), (4, 4), (2, 2), (1, 1), (1, 1))]
+    with pytest.raises(RuntimeError, match='should be the same'):
+        neck(xs)
+    with pytest.raises(arfe_amd.hip.ArfeHipError):          # half CPU tensors: no CPU fallback for the casts either
+        neck([x.half() for x in xs])
