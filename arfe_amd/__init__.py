@@ -11,7 +11,8 @@ from .cnn import ConvModule, constant_init, normal_init, xavier_init
 from .non_local import NonLocal2D
 from .necks import FPN, WFPNDualSpatial
 from .roi_align import RoIAlign
-from .roi_heads import MultiBBoxHead, MultiRoIsBBoxHead, SingleRoIExtractor, StandardRoIHead, get_adaptive_scale_rois
+from .roi_heads import (CascadeRoIHead, MultiBBoxHead, MultiRoIsBBoxHead, SingleRoIExtractor, StandardRoIHead,
+                        get_adaptive_scale_rois)
 from .config import Config
 from .fp16 import auto_fp16, cast_tensor_type, force_fp32, patch_norm_fp32, wrap_fp16_model
 
@@ -19,6 +20,6 @@ __all__ = [
     'BACKBONES', 'DETECTORS', 'HEADS', 'LOSSES', 'NECKS', 'ROI_EXTRACTORS', 'SHARED_HEADS', 'Registry', 'build',
     'build_from_cfg', 'build_head', 'build_neck', 'build_roi_extractor', 'ConvModule', 'constant_init',
     'normal_init', 'xavier_init', 'NonLocal2D', 'WFPNDualSpatial', 'FPN', 'RoIAlign', 'MultiBBoxHead',
-    'MultiRoIsBBoxHead', 'SingleRoIExtractor', 'StandardRoIHead', 'get_adaptive_scale_rois', 'Config', 'auto_fp16', 'force_fp32',
+    'MultiRoIsBBoxHead', 'SingleRoIExtractor', 'StandardRoIHead', 'CascadeRoIHead', 'get_adaptive_scale_rois', 'Config', 'auto_fp16', 'force_fp32',
     'cast_tensor_type', 'patch_norm_fp32', 'wrap_fp16_model',
 ]

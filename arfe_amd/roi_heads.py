@@ -201,3 +201,67 @@ class StandardRoIHead(nn.Module):
 
     def forward_train(self, *a, **k):
         raise NotImplementedError("target assignment / losses are outside the AR-FPN + AR-RFF hot path")
+
+
+@HEADS.register_module()
+class CascadeRoIHead(nn.Module):
+    """The bbox feature path of the reference's CascadeRoIHead (cascade_roi_head.py:16-60 constructor / per-stage module
+    lists, :126-149 `_bbox_forward(stage, x, rois)` with the INTENDED AR-RFF body, a string literal at the reference's HEAD
+    exactly like StandardRoIHead's): one RoI extractor and one MultiRoIsBBoxHead per stage, each stage one pass of the
+    same HIP path.  Box refinement between stages, assigners, samplers, losses and masks are the surrounding framework."""
+
+    def __init__(self, num_stages, stage_loss_weights, bbox_roi_extractor=None, bbox_head=None, mask_roi_extractor=None,
+                 mask_head=None, shared_head=None, train_cfg=None, test_cfg=None):
+        super().__init__()
+        assert bbox_roi_extractor is not None
+        assert bbox_head is not None
+        assert shared_head is None, 'Shared head is not supported in Cascade RCNN anymore'
+        if mask_roi_extractor is not None or mask_head is not None:
+            raise NotImplementedError("mask heads are outside the AR-RFF path")
+        self.num_stages = num_stages
+        self.stage_loss_weights = stage_loss_weights
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.init_bbox_head(bbox_roi_extractor, bbox_head)
+
+    def init_bbox_head(self, bbox_roi_extractor, bbox_head):
+        self.bbox_roi_extractor = nn.ModuleList()
+        self.bbox_head = nn.ModuleList()
+        if not isinstance(bbox_roi_extractor, list):
+            bbox_roi_extractor = [bbox_roi_extractor for _ in range(self.num_stages)]
+        if not isinstance(bbox_head, list):
+            bbox_head = [bbox_head for _ in range(self.num_stages)]
+        assert len(bbox_roi_extractor) == len(bbox_head) == self.num_stages
+        for roi_extractor, head in zip(bbox_roi_extractor, bbox_head):
+            self.bbox_roi_extractor.append(build_roi_extractor(roi_extractor))
+            self.bbox_head.append(build_head(head))
+
+    @property
+    def with_bbox(self):
+        return True
+
+    def init_weights(self, pretrained=None):
+        for i in range(self.num_stages):
+            self.bbox_roi_extractor[i].init_weights()
+            self.bbox_head[i].init_weights()
+
+    def _bbox_forward(self, stage, x, rois):
+        bbox_roi_extractor = self.bbox_roi_extractor[stage]
+        bbox_head = self.bbox_head[stage]
+        rois = rois.float().contiguous()
+        lh_rois, lw_rois = get_adaptive_scale_rois(rois, 1)
+        bbox_feats = bbox_roi_extractor.extract_sets(x[:bbox_roi_extractor.num_inputs], [rois, lw_rois, lh_rois])
+        cls_score, bbox_pred = bbox_head(bbox_feats)
+        return dict(cls_score=cls_score, bbox_pred=bbox_pred, bbox_feats=bbox_feats)
+
+    def forward_dummy(self, x, proposals):
+        """bbox part of cascade_roi_head.py:101-112: every stage on the same proposals."""
+        from .bbox import bbox2roi
+        outs = ()
+        rois = bbox2roi([proposals])
+        for i in range(self.num_stages):
+            r = self._bbox_forward(i, x, rois)
+            outs = outs + (r['cls_score'], r['bbox_pred'])
+        return outs
+
+    def forward_train(self, *a, **k):
+        raise NotImplementedError("target assignment / box refinement / losses are outside the AR-FPN + AR-RFF hot path")

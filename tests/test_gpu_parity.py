@@ -533,6 +533,49 @@ def test_neck_sequence_fpn_then_arfpn_matches_oracle(O, dev):
         assert relerr(v.grad, pf[k].grad) <= TOL_GRAD, k
 
 
+def test_cascade_roi_head_stages_match_oracle(O, dev):
+    """CascadeRoIHead._bbox_forward(stage, x, rois) (cascade_roi_head.py:126-149, intended AR-RFF body): three stages with
+    their own weights on the e2e fixture's pyramid features and RoIs, each against the oracle, forward and gradients."""
+    import arfe_amd
+    d = load_golden('e2e_small.npz')
+    C = d['x0'].shape[1]
+    ext = dict(type='SingleRoIExtractor', roi_layer=dict(type='RoIAlign', out_size=7, sample_num=0), out_channels=C,
+               featmap_strides=[4, 8, 16, 32, 64])
+    head = dict(type='MultiRoIsBBoxHead', in_channels=C, conv_out_channels=C, fc_out_channels=24, roi_feat_size=7,
+                num_classes=80)
+    rh = arfe_amd.build_head(dict(type='CascadeRoIHead', num_stages=3, stage_loss_weights=[1, 0.5, 0.25],
+                                  bbox_roi_extractor=ext, bbox_head=head)).to(dev)
+    g = torch.Generator().manual_seed(9)
+    rh.bbox_head[0].load_state_dict({k[5:]: v for k, v in d.items() if k.startswith('head.')})
+    for st in (1, 2):                                   # the other stages: the same shapes, their own values
+        rh.bbox_head[st].load_state_dict({k[5:]: v + 0.05 * st * torch.randn(v.shape, generator=g)
+                                          for k, v in d.items() if k.startswith('head.')})
+    feats_cpu = [d[f'feat{i}'] for i in range(5)]
+    rois = d['rois']
+    for st in range(3):
+        feats = [f.to(dev).requires_grad_(True) for f in feats_cpu]
+        # later stages see shifted boxes (the reference refines them between stages; any boxes exercise the path)
+        r = rois.clone()
+        r[:, 1:] += 3.0 * st
+        res = rh._bbox_forward(st, feats, r.to(dev))
+        fr = [f.clone().requires_grad_(True) for f in feats_cpu]
+        ph = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in rh.bbox_head[st].state_dict().items()}
+        bf = O.roi_extract3(fr, r)
+        cls, reg = O.rff_head(bf, ph)
+        assert relerr(res['bbox_feats'], bf.detach()) <= TOL, st
+        assert relerr(res['cls_score'], cls.detach()) <= TOL and relerr(res['bbox_pred'], reg.detach()) <= TOL, st
+        c1, c2 = torch.randn(cls.shape, generator=g), torch.randn(reg.shape, generator=g)
+        ((cls * c1).sum() + (reg * c2).sum()).backward()
+        ((res['cls_score'] * c1.to(dev)).sum() + (res['bbox_pred'] * c2.to(dev)).sum()).backward()
+        for i in range(5):
+            ref_g = fr[i].grad if fr[i].grad is not None else torch.zeros_like(fr[i])    # a level no RoI maps to
+            assert relerr(feats[i].grad, ref_g) <= TOL_GRAD, (st, i)
+        for k, v in rh.bbox_head[st].named_parameters():
+            assert relerr(v.grad, ph[k].grad) <= TOL_GRAD, (st, k)
+    outs = rh.forward_dummy([f.to(dev) for f in feats_cpu], rois[:12, 1:].to(dev))
+    assert len(outs) == 6 and outs[0].shape == (12, 81) and outs[5].shape == (12, 320)
+
+
 def test_empty_roi_set_flows_through_extractor_and_head(dev):
     """R = 0 (an image batch without proposals) must give empty outputs and zero gradients, not a crash."""
     import arfe_amd

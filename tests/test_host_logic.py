@@ -210,3 +210,25 @@ def test_fp16_mode_mismatch_and_cpu_refusal():
         neck(xs)
     with pytest.raises(arfe_amd.hip.ArfeHipError):          # half CPU tensors: no CPU fallback for the casts either
         neck([x.half() for x in xs])
+
+
+def test_cascade_roi_head_builds_per_stage_modules():
+    """cascade_roi_head.py:16-60: one extractor/head config broadcast to num_stages, or one per stage; state_dict keys
+    `bbox_head.{stage}.*` as in a reference Cascade R-CNN checkpoint."""
+    ext = dict(type='SingleRoIExtractor', roi_layer=dict(type='RoIAlign', out_size=7, sample_num=0), out_channels=8,
+               featmap_strides=[4, 8, 16, 32, 64])
+    head = dict(type='MultiRoIsBBoxHead', in_channels=8, conv_out_channels=8, fc_out_channels=16, roi_feat_size=7,
+                num_classes=80)
+    rh = arfe_amd.build_head(dict(type='CascadeRoIHead', num_stages=3, stage_loss_weights=[1, 0.5, 0.25],
+                                  bbox_roi_extractor=ext, bbox_head=[dict(head), dict(head), dict(head)]))
+    assert rh.num_stages == 3 and len(rh.bbox_roi_extractor) == 3 and len(rh.bbox_head) == 3
+    assert rh.bbox_head[0] is not rh.bbox_head[1]
+    keys = set(rh.state_dict())
+    assert 'bbox_head.2.wh_conv.conv.weight' in keys and 'bbox_head.0.shared_fcs.1.bias' in keys
+    assert 'bbox_head.1.fc_reg.weight' in keys and len(keys) == 3 * 14
+    rh.init_weights()
+    with pytest.raises(AssertionError):
+        arfe_amd.build_head(dict(type='CascadeRoIHead', num_stages=2, stage_loss_weights=[1, 1], bbox_roi_extractor=ext,
+                                 bbox_head=[dict(head)]))
+    with pytest.raises(NotImplementedError):
+        rh.forward_train()
