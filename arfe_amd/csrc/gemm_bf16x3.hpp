@@ -402,7 +402,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_large_kernel(GemmDims d, L
     // pairs - first the class-1 batches, then the class-0 ones - so that no workgroup is launched only to exit
     // (a grid with 24 idle workgroups beyond the 256 CUs ran the 246 working ones in two rounds).
     int z = blockIdx.z, slice = blockIdx.y;
-    if (d.zk_on) {
+    if (d.zk_on == 2) {
+        const unsigned v = d.zk_pair[blockIdx.y];
+        z = (int)(v >> 8);
+        slice = (int)(v & 255u);
+    } else if (d.zk_on) {
         int p = blockIdx.y, n1 = __builtin_popcount(d.zk_class);
         const bool cls = p < n1 * d.zk_splits1;
         if (!cls) p -= n1 * d.zk_splits1;
@@ -594,19 +598,25 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_large_kernel(GemmDims d, L
         return;
     }
 
-    const int h = lane >> 5;
+    // D layout of a 32x32 block: lane -> column l31, register r -> row (r & 3) + 8 (r >> 2) + 4 (lane >> 5).  The two
+    // column blocks of a wave exchange halves (v_permlane32_swap: upper lanes of the first with lower lanes of the
+    // second), after which one register holds ONE row across the wave's 64 columns: every store / atomic wave-instruction
+    // covers 256 contiguous bytes instead of two 128-byte runs (float atomics run at half rate on those).
+    {
+        const int n = n0 + wn * 64 + lane;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + wn * 64 + j * 32 + l31;
-            if (n >= d.N) continue;
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (m < d.M) epi(z, m, n, acc[i][j][r], first_split);
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[i][0][r]), __float_as_uint(acc[i][1][r]),
+                                                                 false, false);
+                const int m = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2);
+                if (n < d.N) {
+                    if (m < d.M) epi(z, m, n, __uint_as_float(sw[0]), first_split);
+                    if (m + 4 < d.M) epi(z, m + 4, n, __uint_as_float(sw[1]), first_split);
+                }
             }
-        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -882,7 +892,8 @@ static inline int32_t launch_gemm_auto(int M, int N, int K, int kb_count, int ba
         splitk = splitk_large;
         d.splitk = splitk;
         if (zvar) {                      // the caller planned steps and slices per batch (plan_large_tile said yes)
-            d.zk_on = 1;
+            d.zk_on = zvar->zk_on == 2 ? 2 : 1;
+            if (d.zk_on == 2) memcpy(d.zk_pair, zvar->zk_pair, sizeof(d.zk_pair));
             d.zk_class = zvar->zk_class;
             d.zk_steps0 = zvar->zk_steps0; d.zk_steps1 = zvar->zk_steps1;
             d.zk_splits0 = zvar->zk_splits0; d.zk_splits1 = zvar->zk_splits1;

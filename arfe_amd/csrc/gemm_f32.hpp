@@ -36,6 +36,9 @@ struct GemmDims {
     int zk_on = 0;
     unsigned zk_class = 0;
     int zk_steps0 = 0, zk_steps1 = 0, zk_splits0 = 0, zk_splits1 = 0;
+    // zk_on == 2: gridDim.y indexes this table of (batch << 8 | slice) pairs instead of the class-major order, so that the
+    // caller decides which pairs share an XCD (workgroup id modulo 8) and with it an L2
+    unsigned short zk_pair[256] = {};
 };
 
 // ---- operand loaders: return A(m,k) / B(k,n) for batch z and k-batch kb, 0 outside the matrix ------------

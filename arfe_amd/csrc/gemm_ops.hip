@@ -1,5 +1,6 @@
 // Dense contractions of the AR path on the exact-fp32 MFMA GEMM (gemm_f32.hpp):
 //   NonLocal2D refine fwd/bwd, AR-RFF 3x3 convs (implicit GEMM) fwd/bwd, nn.Linear fwd/bwd.
+#include <algorithm>
 #include "gemm_bf16x3.hpp"
 
 namespace arfe {
@@ -569,6 +570,30 @@ extern "C" int32_t arfe_conv3x3_bwd_weight(int32_t R, int32_t C, const float* x,
         zv.zk_class = 0x38u;                                              // taps 3,4,5 (dy = 0): 7 pixel rows
         zv.zk_steps0 = steps6; zv.zk_splits0 = slices(steps6);
         zv.zk_steps1 = steps7; zv.zk_splits1 = slices(steps7);
+        // Which (tap, slice) pairs share an XCD: the nine taps read the SAME x and dy rows of a K range, so the pairs are
+        // ordered by where their slice starts in K and each XCD (workgroup id modulo 8) takes a contiguous run of that order -
+        // its L2 then serves the other taps' reads of a range (class-major order: every tap's slice on another XCD, x and dy
+        // crossed the fabric nine times, 843 MB per launch by the PMC counters).
+        {
+            struct Pair { double key; int z, s; };
+            Pair pr[256];
+            int np = 0;
+            for (int z = 0; z < 9; ++z) {
+                const int sp = ((zv.zk_class >> z) & 1u) ? zv.zk_splits1 : zv.zk_splits0;
+                for (int sl = 0; sl < sp; ++sl) pr[np++] = Pair{(double)sl / sp, z, sl};
+            }
+            if (np <= 256 && zv.zk_splits0 < 256 && zv.zk_splits1 < 256) {
+                std::stable_sort(pr, pr + np, [](const Pair& a, const Pair& b) { return a.key < b.key; });
+                int start = 0;
+                for (int c = 0; c < 8; ++c) {
+                    const int cnt = (np - c + 7) / 8;                 // workgroups y = c, c + 8, ... < np
+                    for (int r = 0; r < cnt; ++r)
+                        zv.zk_pair[8 * r + c] = (unsigned short)((pr[start + r].z << 8) | pr[start + r].s);
+                    start += cnt;
+                }
+                zv.zk_on = 2;
+            }
+        }
         rc = launch_gemm_auto(C, C, steps7 * bk, 1, 9, 64, la, lb, e, st, false, false, &zv);
     } else {
         const int Kp = R * 56;

@@ -28,6 +28,21 @@ PEAK_HBM_GBS = 8000.0            # spec; ~6300 GB/s achievable by a float4 copy
 ARFPN_HBM_BYTES_PER_IMG = 458.4e6   # fwd 2 x 91.67 MB + bwd 3 x 91.67 MB
 
 
+def path_roofline(batch, rois_per_img, step_s):
+    """SURVEY §8(d)'s whole-path figure: t_roof = sum over stages of max(bytes / 8 TB/s, flops / peak) from the table's
+    ALGORITHMIC work per image (AR-FPN streaming stages 458.4 MB; NonLocal 20.4 + 49 GFLOP; AR-RFF convs + FCs
+    103.5 + 207 GFLOP at 512 RoIs/img), achieved = t_roof / t_measured - against the exact-fp32 MFMA peak (what an fp32
+    implementation is bounded by) and against the dense bf16 peak (the pipe the bf16x3 contractions run on)."""
+    gflop = 69.4 + 310.5 * rois_per_img / 512.0
+    t_hbm = ARFPN_HBM_BYTES_PER_IMG / (PEAK_HBM_GBS * 1e9)
+    t32 = batch * (t_hbm + gflop * 1e9 / (PEAK_F32_MFMA_TFLOPS * 1e12))
+    t16 = batch * (t_hbm + gflop * 1e9 / (PEAK_BF16_MFMA_TFLOPS * 1e12))
+    return {"definition": "t_roof / t_measured, SURVEY 8(d) algorithmic bytes and flops per image",
+            "algorithmic_gflop_per_img": round(gflop, 1), "algorithmic_hbm_bytes_per_img": ARFPN_HBM_BYTES_PER_IMG,
+            "t_roof_ms_fp32_mfma": round(t32 * 1e3, 4), "achieved_vs_fp32_mfma": round(t32 / step_s, 4),
+            "t_roof_ms_bf16_mfma": round(t16 * 1e3, 4), "achieved_vs_bf16_mfma": round(t16 / step_s, 4)}
+
+
 def pmc_traffic(kernel_substr):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE doubled as
     the gfx950 note in MI355X_MICROARCH.md prescribes, + WRITE_SIZE; tools/pmc_run.sh + tools/pmc_traffic.py on this
@@ -217,6 +232,7 @@ def main():
                                     "achieved": round(hbm_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                     "frac": round(hbm_gbs / PEAK_HBM_GBS, 4), "ms_per_step": round(fpn_ms, 4),
                                     "algorithmic_bytes_per_img": ARFPN_HBM_BYTES_PER_IMG},
+            "roofline_path": path_roofline(B, args.rois_per_img, elapsed / args.steps),
             "stage_ms_per_step": {"arfpn_hbm_stages": round(fpn_ms, 4), "nonlocal_fwd_bwd": round(nl_ms, 4),
                                   "conv3x3_fwd_and_dgrad": round(sum(conv_ms) / args.steps, 4)},
         }
