@@ -192,7 +192,7 @@ def main():
 
     if rank == 0:
         imgs = world * B * args.steps
-        # dominant kernel: the implicit-GEMM 3x3 conv (gemm_f32_kernel<LoadRowMajorK, ConvGatherB, EpiConv>),
+        # dominant kernel: the implicit-GEMM 3x3 conv (gemm_bf16x3_n224_kernel<LoadSplitK, ConvGatherB, EpiConv>),
         # 3 forward + 3 data-gradient launches per step, each 2*C*C*9 * R*49 flop
         conv_ms = probes.get('conv3x3_fwd', []) + probes.get('conv3x3_bwd_data', [])
         conv_flop = 2.0 * 256 * 256 * 9 * R * 49
