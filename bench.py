@@ -68,7 +68,9 @@ def parse():
     ap.add_argument('--batch', type=int, default=2, help='images per GPU (BASELINE config: bs=2)')
     ap.add_argument('--rois-per-img', type=int, default=512)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-iters', type=int, default=3)
+    ap.add_argument('--cpu-iters', type=int, default=5)
+    ap.add_argument('--fp16', action='store_true',
+                    help="the reference's fp16 mode (wrap_fp16_model): half storage at module boundaries, fp32 kernels")
     return ap.parse_args()
 
 
@@ -151,11 +153,19 @@ def main():
     neck_state = {k: v.detach().cpu().clone() for k, v in neck.state_dict().items()}
     head_state = {k: v.detach().cpu().clone() for k, v in roi_head.bbox_head.state_dict().items()}
     B, R = args.batch, args.batch * args.rois_per_img
-    xs = [x.to(dev).requires_grad_(True) for x in O.synth_pyramid(B, 256, seed=1234 + rank)]
+    xs = [x.to(dev) for x in O.synth_pyramid(B, 256, seed=1234 + rank)]
+    if args.fp16:                                   # SURVEY 8(d) fp16 variant: same tensors .half()
+        import arfe_amd
+        arfe_amd.wrap_fp16_model(neck)
+        arfe_amd.wrap_fp16_model(roi_head)
+        xs = [x.half() for x in xs]
+    xs = [x.requires_grad_(True) for x in xs]
     rois = O.synth_rois(B, args.rois_per_img, seed=1234 + rank).to(dev)
     g = torch.Generator().manual_seed(99 + rank)
     cot_cls = torch.randn(R, 81, generator=g).to(dev)
     cot_reg = torch.randn(R, 320, generator=g).to(dev)
+    if args.fp16:
+        cot_cls, cot_reg = cot_cls.half(), cot_reg.half()
     # gradients become ready head-first, then the neck
     reducer = GradAllReducer([list(roi_head.bbox_head.parameters()), list(neck.parameters())])
 
@@ -210,7 +220,8 @@ def main():
             "value": round(imgs / elapsed, 3), "unit": "imgs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if f32_mode else "f32 (dense contractions as bf16x3 split MFMA, fp32 accumulate)",
+            "dtype": ("f16 storage at module boundaries, " if args.fp16 else "") +
+                     ("f32" if f32_mode else "f32 (dense contractions as bf16x3 split MFMA, fp32 accumulate)"),
             "data": "synthetic",
             "config": {"workload": "Faster R-CNN R50 AR-FPN + AR-RFF hot path (BASELINE configs[2]): WFPNDualSpatial "
                                    "(refine_level 2) + 3-RoI RoIAlign + MultiRoIsBBoxHead, fwd+bwd + grad all-reduce",
@@ -236,7 +247,7 @@ def main():
             "stage_ms_per_step": {"arfpn_hbm_stages": round(fpn_ms, 4), "nonlocal_fwd_bwd": round(nl_ms, 4),
                                   "conv3x3_fwd_and_dgrad": round(sum(conv_ms) / args.steps, 4)},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.fp16:
             out["cpu_baseline"] = cpu_baseline(B, args.rois_per_img, args.cpu_iters, neck_state, head_state)
         print(json.dumps(out), flush=True)
     if world > 1:
