@@ -3,12 +3,11 @@ import torch
 
 
 def bbox2roi(bbox_list):
-    rois_list = []
-    for img_id, bboxes in enumerate(bbox_list):
-        if bboxes.size(0) > 0:
-            img_inds = bboxes.new_full((bboxes.size(0), 1), img_id)
-            rois = torch.cat([img_inds, bboxes[:, :4]], dim=-1)
-        else:
-            rois = bboxes.new_zeros((0, 5))
-        rois_list.append(rois)
-    return torch.cat(rois_list, 0)
+    """Concatenates the per-image box tensors ([n_i, >=4]) into one RoI tensor whose first column is the image index;
+    an image without boxes contributes no rows."""
+    parts = []
+    for index, boxes in enumerate(bbox_list):
+        xyxy = boxes[:, :4]
+        batch_col = torch.full((xyxy.shape[0], 1), float(index), dtype=xyxy.dtype, device=xyxy.device)
+        parts.append(torch.cat((batch_col, xyxy), dim=1))
+    return torch.cat(parts, dim=0)

@@ -22,15 +22,15 @@ def _to(t, dst_type):
 
 
 def cast_tensor_type(inputs, src_type, dst_type):
-    if isinstance(inputs, torch.Tensor):
-        return _to(inputs, dst_type)      # like the reference, every tensor is converted; src_type is not consulted
-    if isinstance(inputs, (str, np.ndarray)):
+    """Converts every tensor inside a (nested) container to `dst_type`.  `src_type` is accepted for signature
+    compatibility only: like the reference's helper, the conversion does not look at the dtype a tensor has."""
+    if torch.is_tensor(inputs):
+        return _to(inputs, dst_type)
+    if isinstance(inputs, (str, np.ndarray)) or not isinstance(inputs, abc.Iterable):
         return inputs
     if isinstance(inputs, abc.Mapping):
-        return type(inputs)({k: cast_tensor_type(v, src_type, dst_type) for k, v in inputs.items()})
-    if isinstance(inputs, abc.Iterable):
-        return type(inputs)(cast_tensor_type(item, src_type, dst_type) for item in inputs)
-    return inputs
+        return type(inputs)({key: cast_tensor_type(val, src_type, dst_type) for key, val in inputs.items()})
+    return type(inputs)(cast_tensor_type(val, src_type, dst_type) for val in inputs)
 
 
 def _cast_call(old_func, apply_to, src, dst, out_cast, args, kwargs):
@@ -69,27 +69,26 @@ def force_fp32(apply_to=None, out_fp16=False):
 
 
 def patch_forward_method(func, src_type, dst_type, convert_output=True):
+    """forward wrapper: arguments converted to dst_type, the result (optionally) back to src_type."""
     def new_forward(*args, **kwargs):
-        output = func(*cast_tensor_type(args, src_type, dst_type), **cast_tensor_type(kwargs, src_type, dst_type))
-        if convert_output:
-            output = cast_tensor_type(output, dst_type, src_type)
-        return output
+        out = func(*cast_tensor_type(args, src_type, dst_type), **cast_tensor_type(kwargs, src_type, dst_type))
+        return cast_tensor_type(out, dst_type, src_type) if convert_output else out
     return new_forward
 
 
 def patch_norm_fp32(module):
-    if isinstance(module, (nn.modules.batchnorm._BatchNorm, nn.GroupNorm)):
-        module.float()
-        if isinstance(module, nn.GroupNorm):
-            module.forward = patch_forward_method(module.forward, torch.half, torch.float)
-    for child in module.children():
-        patch_norm_fp32(child)
+    """Normalisation layers stay in fp32 inside a half model; GroupNorm additionally gets a half<->float forward."""
+    for m in module.modules():
+        if isinstance(m, (nn.modules.batchnorm._BatchNorm, nn.GroupNorm)):
+            m.float()
+            if isinstance(m, nn.GroupNorm):
+                m.forward = patch_forward_method(m.forward, torch.half, torch.float)
     return module
 
 
 def wrap_fp16_model(model):
-    model.half()
-    patch_norm_fp32(model)
+    """Half parameters (norm layers excepted) and `fp16_enabled = True` on every module that declares the attribute."""
+    patch_norm_fp32(model.half())
     for m in model.modules():
         if hasattr(m, 'fp16_enabled'):
             m.fp16_enabled = True

@@ -224,16 +224,13 @@ class CascadeRoIHead(nn.Module):
         self.init_bbox_head(bbox_roi_extractor, bbox_head)
 
     def init_bbox_head(self, bbox_roi_extractor, bbox_head):
-        self.bbox_roi_extractor = nn.ModuleList()
-        self.bbox_head = nn.ModuleList()
-        if not isinstance(bbox_roi_extractor, list):
-            bbox_roi_extractor = [bbox_roi_extractor for _ in range(self.num_stages)]
-        if not isinstance(bbox_head, list):
-            bbox_head = [bbox_head for _ in range(self.num_stages)]
-        assert len(bbox_roi_extractor) == len(bbox_head) == self.num_stages
-        for roi_extractor, head in zip(bbox_roi_extractor, bbox_head):
-            self.bbox_roi_extractor.append(build_roi_extractor(roi_extractor))
-            self.bbox_head.append(build_head(head))
+        """One extractor and one head per stage; a single config dict stands for every stage."""
+        def per_stage(cfg, what):
+            cfgs = list(cfg) if isinstance(cfg, (list, tuple)) else [cfg] * self.num_stages
+            assert len(cfgs) == self.num_stages, f"{what}: {len(cfgs)} configs for {self.num_stages} stages"
+            return cfgs
+        self.bbox_roi_extractor = nn.ModuleList(build_roi_extractor(c) for c in per_stage(bbox_roi_extractor, 'bbox_roi_extractor'))
+        self.bbox_head = nn.ModuleList(build_head(c) for c in per_stage(bbox_head, 'bbox_head'))
 
     @property
     def with_bbox(self):
