@@ -191,18 +191,27 @@ __global__ void reduce_mid_kernel(const float* __restrict__ x, const float* __re
     int o0 = blockIdx.y * outer_chunk;
     int o1 = o0 + outer_chunk < outer ? o0 + outer_chunk : outer;
     float s = 0.f;
-    // short rows (the 49 pixels of an RoI channel): one wave per row, four rows in flight per workgroup; long rows
-    // (NonLocal, inner = L): the whole workgroup along the row
-    const bool short_rows = inner <= 64;
-    const int ostep = short_rows ? (int)(blockDim.x >> 6) : 1, istep = short_rows ? 64 : (int)blockDim.x;
-    const int ofirst = short_rows ? (int)(threadIdx.x >> 6) : 0, ifirst = short_rows ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
-    for (int o = o0 + ofirst; o < o1; o += ostep) {
-        const float* row = x + (int64_t)o * outer_stride + (int64_t)mid * inner;
-        const float* mrow = mask ? mask + (int64_t)o * outer_stride + (int64_t)mid * inner : nullptr;
-        for (int i = ifirst; i < inner; i += istep) {
-            float v = row[i];
-            if (mrow && !(mrow[i] > 0.f)) v = 0.f;
+    if (inner <= 64) {
+        // short rows (the 49 pixels of an RoI channel): the (row, pixel) pairs of the chunk are dealt flat over the
+        // workgroup, so every thread has several independent loads in flight (one wave per row ran at 1.8 TB/s)
+        const int n = (o1 - o0) * inner;
+        for (int e = threadIdx.x; e < n; e += blockDim.x) {
+            const int o = e / inner, i = e - o * inner;
+            const int64_t off = (int64_t)(o0 + o) * outer_stride + (int64_t)mid * inner + i;
+            float v = x[off];
+            if (mask && !(mask[off] > 0.f)) v = 0.f;
             s += v;
+        }
+    } else {
+        // long rows (NonLocal, inner = L): the whole workgroup along the row
+        for (int o = o0; o < o1; ++o) {
+            const float* row = x + (int64_t)o * outer_stride + (int64_t)mid * inner;
+            const float* mrow = mask ? mask + (int64_t)o * outer_stride + (int64_t)mid * inner : nullptr;
+            for (int i = threadIdx.x; i < inner; i += blockDim.x) {
+                float v = row[i];
+                if (mrow && !(mrow[i] > 0.f)) v = 0.f;
+                s += v;
+            }
         }
     }
     s = wave_sum(s);
@@ -223,6 +232,7 @@ __global__ void colsum_kernel(const float* __restrict__ x, const float* __restri
     int r0 = blockIdx.y * row_chunk;
     int r1 = r0 + row_chunk < rows ? r0 + row_chunk : rows;
     float s = 0.f;
+#pragma unroll 8
     for (int r = r0; r < r1; ++r) {
         float v = x[(int64_t)r * cols + c];
         if (mask && !(mask[(int64_t)r * cols + c] > 0.f)) v = 0.f;
@@ -468,7 +478,7 @@ extern "C" int32_t arfe_linear_bwd(int32_t R, int32_t in_f, int32_t out_f, const
         if (rc) return rc;
     }
     if (db) {
-        int chunk = 64;
+        int chunk = 16;                        // 256 workgroups at R = 1024, out_f = 1024
         dim3 grid(cdiv(out_f, 256), cdiv(R, chunk));
         hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, st, dy, (const float*)nullptr, db, R, out_f, chunk);
         ARFE_CHECK_LAUNCH();
@@ -602,9 +612,9 @@ extern "C" int32_t arfe_conv3x3_bwd_weight(int32_t R, int32_t C, const float* x,
     if (rc) return rc;
     hipLaunchKernelGGL(conv_dw_unpermute_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, dwp, dw, C);
     ARFE_CHECK_LAUNCH();
-    int chunk = 32;
+    int chunk = 64;
     dim3 grid(C, cdiv(R, chunk));
-    hipLaunchKernelGGL(reduce_mid_kernel, grid, dim3(64), 0, st, dy, (const float*)nullptr, db, R, dy_roi_stride, 49, chunk);
+    hipLaunchKernelGGL(reduce_mid_kernel, grid, dim3(256), 0, st, dy, (const float*)nullptr, db, R, dy_roi_stride, 49, chunk);
     ARFE_CHECK_LAUNCH();
     return ARFE_OK;
 }
