@@ -395,14 +395,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x6_kernel(GemmDims d, LA la, 
 // + 32 staging registers), which is what keeps the two halves from overlapping further.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int XL_BM = 256, XL_BN = 256;
-constexpr int XL_LDS_BYTES = 2 * 2 * (XL_BM + XL_BN) * XB_LD * 2;      // 163840
+constexpr int XL_LDS_BYTES = 2 * 2 * (XL_BM + XL_BN) * XS_LD * 2;      // 131 072 (swizzled 64-byte rows, see xs_swz)
 
 template <class LA, class LB, class EPI>
 __global__ __launch_bounds__(512, 2) void gemm_bf16x3_large_kernel(GemmDims d, LA la, LB lb, EPI epi) {
     extern __shared__ __attribute__((aligned(16))) unsigned short xl_lds[];
     // buffer b: A_hi [256][40] | A_lo | B_hi | B_lo
     auto img = [&](int buf, int which) -> unsigned short* {
-        return xl_lds + ((size_t)buf * 4 + which) * (XL_BM * XB_LD);
+        return xl_lds + ((size_t)buf * 4 + which) * (XL_BM * XS_LD);
     };
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -469,10 +469,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_large_kernel(GemmDims d, L
     }
     typename LA::Row arow[2];
     typename LB::Row brow[2];
+    int a_off[2], b_off[2];          // swizzled element offsets of this thread's staging octets inside an image
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         arow[i] = la.row(z, m0 + a_row[i]);
         brow[i] = lb.row(z, n0 + b_row[i]);
+        a_off[i] = a_row[i] * XS_LD + 8 * (a_oct[i] ^ xs_swz(a_row[i]));
+        b_off[i] = b_row[i] * XS_LD + 8 * (b_oct[i] ^ xs_swz(b_row[i]));
     }
     float ra[2][8], rb[2][8];
     auto fetch = [&](int step) {
@@ -500,10 +503,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_large_kernel(GemmDims d, L
         f_kb = d.kb_inner ? step % d.kb_count : step / ksteps_per_kb;
         f_ks = d.kb_inner ? step / d.kb_count : step - f_kb * ksteps_per_kb;
     };
-    auto fetch_full = [&]() {
-        const int kb = f_kb, k0 = f_ks * XB_BK;
+    auto fetch_full_a = [&]() {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) la.template load8<true>(arow[i], z, kb, k0 + 8 * a_oct[i], ra[i]);
+        for (int i = 0; i < 2; ++i) la.template load8<true>(arow[i], z, f_kb, f_ks * XB_BK + 8 * a_oct[i], ra[i]);
+    };
+    auto fetch_full_b = [&]() {
+        const int kb = f_kb, k0 = f_ks * XB_BK;
 #pragma unroll
         for (int i = 0; i < 2; ++i) lb.template load8<true>(brow[i], z, kb, k0 + 8 * b_oct[i], rb[i]);
         // advance to the next step
@@ -522,8 +527,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_large_kernel(GemmDims d, L
         for (int i = 0; i < 2; ++i) {
             bf16x8 hi, lo;
             stage8<LA>(ra[i], hi, lo);
-            *reinterpret_cast<bf16x8*>(img(buf, 0) + a_row[i] * XB_LD + 8 * a_oct[i]) = hi;
-            *reinterpret_cast<bf16x8*>(img(buf, 1) + a_row[i] * XB_LD + 8 * a_oct[i]) = lo;
+            *reinterpret_cast<bf16x8*>(img(buf, 0) + a_off[i]) = hi;
+            *reinterpret_cast<bf16x8*>(img(buf, 1) + a_off[i]) = lo;
         }
     };
     auto stash_b = [&](int buf) {
@@ -531,24 +536,25 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_large_kernel(GemmDims d, L
         for (int i = 0; i < 2; ++i) {
             bf16x8 hi, lo;
             stage8<LB>(rb[i], hi, lo);
-            *reinterpret_cast<bf16x8*>(img(buf, 2) + b_row[i] * XB_LD + 8 * b_oct[i]) = hi;
-            *reinterpret_cast<bf16x8*>(img(buf, 3) + b_row[i] * XB_LD + 8 * b_oct[i]) = lo;
+            *reinterpret_cast<bf16x8*>(img(buf, 2) + b_off[i]) = hi;
+            *reinterpret_cast<bf16x8*>(img(buf, 3) + b_off[i]) = lo;
         }
     };
     const int kh = lane >> 5, l31 = lane & 31;
+    const int fsw = xs_swz(l31);       // fragment row bases are multiples of 32: the row's swizzle is the lane's
     auto mma = [&](int buf, int kk) {
         bf16x8 ah[4], al[4], bh[2], bl[2];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int ar = wm * 128 + t * 32 + l31;
-            ah[t] = *reinterpret_cast<const bf16x8*>(img(buf, 0) + ar * XB_LD + kk + 8 * kh);
-            al[t] = *reinterpret_cast<const bf16x8*>(img(buf, 1) + ar * XB_LD + kk + 8 * kh);
+            ah[t] = *reinterpret_cast<const bf16x8*>(img(buf, 0) + ar * XS_LD + 8 * (((kk >> 3) + kh) ^ fsw));
+            al[t] = *reinterpret_cast<const bf16x8*>(img(buf, 1) + ar * XS_LD + 8 * (((kk >> 3) + kh) ^ fsw));
         }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int br = wn * 64 + t * 32 + l31;
-            bh[t] = *reinterpret_cast<const bf16x8*>(img(buf, 2) + br * XB_LD + kk + 8 * kh);
-            bl[t] = *reinterpret_cast<const bf16x8*>(img(buf, 3) + br * XB_LD + kk + 8 * kh);
+            bh[t] = *reinterpret_cast<const bf16x8*>(img(buf, 2) + br * XS_LD + 8 * (((kk >> 3) + kh) ^ fsw));
+            bl[t] = *reinterpret_cast<const bf16x8*>(img(buf, 3) + br * XS_LD + 8 * (((kk >> 3) + kh) ^ fsw));
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -576,10 +582,15 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_large_kernel(GemmDims d, L
             // ping-pong order in which SIMD partner waves alternate MFMA and staging halves, were both measured slower)
             fetch_seek(s + 2);
             for (; s + 2 < s_end; ++s) {
+                // each operand's loads for step s + 2 go out as soon as its staging registers are free and are pinned
+                // ahead of the MFMAs that follow (the scheduler otherwise sinks them behind the last MFMA, see n224)
                 stash_a(buf ^ 1);
+                fetch_full_a();
+                __builtin_amdgcn_sched_barrier(0);
                 mma(buf, 0);
                 stash_b(buf ^ 1);
-                fetch_full();
+                fetch_full_b();
+                __builtin_amdgcn_sched_barrier(0);
                 mma(buf, 16);
                 __syncthreads();
                 buf ^= 1;
