@@ -653,6 +653,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_large_kernel(GemmDims d, L
 // 256 CUs become 224 workgroups of 7/8 the work.  8 waves as 4(M) x 2(N), wave tile 64 x 112 = 4 x 7 blocks of
 // v_mfma_f32_16x16x32_bf16 (one instruction spans the whole 32-wide K-step; 112 accumulator registers).  Full K-steps
 // only (K a multiple of 32), otherwise the same pipeline as above.
+// (Tried: the same tile as 8 x 1 waves of 32 x 224 on v_mfma_f32_32x32x16_bf16, whose 32-cycle gaps leave more vector
+// issue for the staging code - 238 us against 220: every wave then reads all of B from LDS.)
 // ---------------------------------------------------------------------------------------------------------
 constexpr int XN_BN = 224;
 constexpr int XN_BUF = 2 * (XL_BM + XN_BN) * XS_LD;                 // bf16 elements per buffer: A_hi A_lo B_hi B_lo
