@@ -144,6 +144,10 @@ def main():
         else:
             dist.init_process_group(backend=backend)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world > 1:
+        # communicator set-up (lazy in RCCL) must not land in the timed region even with --warmup 0
+        dist.all_reduce(torch.zeros(1, device=dev))
+        torch.cuda.synchronize()
 
     from arfe_amd import functional as Fn
     from arfe_amd.dist import GradAllReducer
