@@ -433,6 +433,30 @@ __global__ __launch_bounds__(256) void roialign_fwd_sep_kernel(RoiLevels L, RoiS
 constexpr int RB_NB = 4;
 constexpr int RB_SEGS = 4;        // slices of a long RoI list
 constexpr int RB_SEG_MIN = 32;    // lists up to this length stay in one workgroup (plain stores)
+// Only the tiles whose RoI list is cut into slices are summed with atomics and need a zeroed output: every other tile
+// (the empty ones included) is stored exactly once by the tile kernel.  Zeroing just those replaces a fill of the whole
+// pyramid gradient (183 MB per launch at the bench size).
+__global__ __launch_bounds__(256) void roi_zero_sliced_tiles_kernel(RoiLevels L, RoiTileTable T, const int* __restrict__ offsets,
+                                                                    int ntiles, int nchunks) {
+    const int tile = (int)(blockIdx.x / (unsigned)nchunks);
+    if (offsets[tile + 1] - offsets[tile] <= RB_SEG_MIN) return;
+    int lvl = 0;
+    while (lvl + 1 < L.n && tile >= T.first[lvl + 1]) ++lvl;
+    const int local = tile - T.first[lvl];
+    const int tx = local % T.tiles_x[lvl];
+    const int ty = (local / T.tiles_x[lvl]) % T.tiles_y[lvl];
+    const int b = local / (T.tiles_x[lvl] * T.tiles_y[lvl]);
+    const int H = L.H[lvl], W = L.W[lvl];
+    const int c0 = (int)(blockIdx.x % (unsigned)nchunks) * RB_CC;
+    float* d = L.dfeat[0];
+#pragma unroll
+    for (int i = 1; i < ARFE_MAX_LEVELS; ++i) if (i == lvl) d = L.dfeat[i];
+    const int ox = tx * RT + (threadIdx.x & 15), oy = ty * RT + (threadIdx.x >> 4);
+    if (ox >= W || oy >= H) return;
+    for (int c = c0; c < c0 + RB_CC && c < L.C; ++c) d[(((int64_t)b * L.C + c) * H + oy) * W + ox] = 0.f;
+    (void)ntiles;
+}
+
 static_assert(RB_CC == 16 && RT == 16, "the MFMA tiles are 16x16: a wave owns 4 of the 16 channels, a tile is 16x16 pixels");
 __global__ __launch_bounds__(256) void roialign_bwd_tiles_kernel(RoiLevels L, RoiSets S, RoiTileTable T, int P, int sample_num,
                                                                  const float* __restrict__ gout, int64_t g_roi_stride,
@@ -783,10 +807,9 @@ extern "C" int32_t arfe_roialign_bwd(const arfe_pyramid_t* pyr, float* const* df
     RoiWeightHdr* hdr = (RoiWeightHdr*)after;
     float* wtab = (float*)(hdr + nroi_all);
     hipStream_t st = as_stream(stream);
-    {   // one launch: the tile counters and the gradient maps (tiles whose list is cut into slices accumulate atomically)
+    {   // the tile counters (the gradient maps: see roi_zero_sliced_tiles_kernel)
         ZeroList z;
         z.add(counts, ntiles);
-        for (int i = 0; i < L.n; ++i) z.add(L.dfeat[i], (int64_t)L.B * L.C * L.H[i] * L.W[i]);
         rc = zero_buffers(z, st);
         if (rc) return rc;
     }
@@ -808,6 +831,9 @@ extern "C" int32_t arfe_roialign_bwd(const arfe_pyramid_t* pyr, float* const* df
     }
     const int nchunks = cdiv(L.C, RB_CC);
     ARFE_CHECK_ARG((int64_t)ntiles * nchunks < (int64_t)1 << 31, ARFE_ERR_ARG, "roialign_bwd: pyramid too large");
+    hipLaunchKernelGGL(roi_zero_sliced_tiles_kernel, dim3(ntiles * nchunks), dim3(256), 0, st, L, T, (const int*)offsets, ntiles,
+                       nchunks);
+    ARFE_CHECK_LAUNCH();
     hipLaunchKernelGGL(roialign_bwd_tiles_kernel, dim3(ntiles * nchunks, 1, RB_SEGS), dim3(256), 0, st, L, S, T, pooled,
                        sample_num, gout, gout_roi_stride, (const int*)offsets, (const int*)list, (const int*)lmeta,
                        (const float*)wtab, ntiles, nchunks);

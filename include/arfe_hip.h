@@ -140,8 +140,8 @@ int32_t arfe_roialign_fwd(const arfe_pyramid_t* pyr, const float* const* feats, 
                           void* workspace, void* stream);
 
 /* dfeats[i] = sum over all `nsets` RoI sets of RoIAlign^T(gout slice of that set): every element of every
- * dfeats[i] is written by the call (zero-filled first; a 16x16 tile whose RoI list is long is summed by a few
- * workgroups with float atomics, every other tile is stored once).  Set s reads its upstream
+ * dfeats[i] is written by the call (a 16x16 tile whose RoI list is long is zeroed and summed by a few workgroups
+ * with float atomics, every other tile - the empty ones included - is stored exactly once).  Set s reads its upstream
  * gradient at gout + k*gout_roi_stride + (s*C + c)*49 + p (the [R, nsets*C, 7, 7] concat gradient).
  * RoIs are binned per 16x16 feature tile in `workspace` (arfe_roialign_bwd_workspace_bytes). pooled must be 7. */
 int64_t arfe_roialign_bwd_workspace_bytes(const arfe_pyramid_t* pyr, int32_t nsets, int32_t R);

@@ -22,6 +22,18 @@ def rel(a, b):
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item(), ((a - b).norm() / b.norm().clamp_min(1e-300)).item()
 
 
+def poison():
+    """NaN-fill the caching allocator's free blocks on both streams: any output element a kernel leaves unwritten (or any
+    read of uninitialised workspace) then shows up as NaN in the comparison."""
+    from arfe_amd import functional as Fn
+    for st in (torch.cuda.current_stream(), Fn.side_stream(dev)):
+        with torch.cuda.stream(st):
+            junk = [torch.full((1 << 22,), float('nan'), device=dev) for _ in range(48)]
+            junk += [torch.full((n,), float('nan'), device=dev) for n in (64, 1024, 16384, 262144) for _ in range(32)]
+            del junk
+    torch.cuda.synchronize()
+
+
 worst = 0.0
 for ci, (B, C, fc, sizes, R, r) in enumerate(CASES):
     g = torch.Generator().manual_seed(100 + ci)
@@ -56,6 +68,7 @@ for ci, (B, C, fc, sizes, R, r) in enumerate(CASES):
     c1, c2 = torch.randn(cls_r.shape, generator=g), torch.randn(reg_r.shape, generator=g)
     ((cls_r * c1).sum() + (reg_r * c2).sum()).backward()
     xs = [x.clone().to(dev).requires_grad_(True) for x in xs_cpu]
+    poison()
     res = roi_head._bbox_forward(neck(xs), rois.to(dev))
     ((res['cls_score'] * c1.to(dev)).sum() + (res['bbox_pred'] * c2.to(dev)).sum()).backward()
     torch.cuda.synchronize()
