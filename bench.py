@@ -63,8 +63,8 @@ def pmc_traffic(kernel_substr):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch', type=int, default=2, help='images per GPU (BASELINE config: bs=2)')
     ap.add_argument('--rois-per-img', type=int, default=512)
     ap.add_argument('--no-cpu-baseline', action='store_true')
