@@ -632,6 +632,32 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_large_kernel(GemmDims d, L
     // covers 256 contiguous bytes instead of two 128-byte runs (float atomics run at half rate on those).
     {
         const int n = n0 + wn * 64 + lane;
+        if constexpr (epi_has_pre<EPI>::value) {
+            if (epi.wants_pre()) {                 // wave-uniform: auxiliary operands of a 32-row block first, then the stores
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float ps[16][2], pd[16][2];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2);
+                        const int nc = n < d.N ? n : d.N - 1;
+                        epi.pre(z, m < d.M ? m : d.M - 1, nc, ps[r][0], pd[r][0]);
+                        epi.pre(z, m + 4 < d.M ? m + 4 : d.M - 1, nc, ps[r][1], pd[r][1]);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[i][0][r]),
+                                                                         __float_as_uint(acc[i][1][r]), false, false);
+                        const int m = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2);
+                        if (n < d.N) {
+                            if (m < d.M) epi.store_pre(z, m, n, __uint_as_float(sw[0]), ps[r][0], pd[r][0]);
+                            if (m + 4 < d.M) epi.store_pre(z, m + 4, n, __uint_as_float(sw[1]), ps[r][1], pd[r][1]);
+                        }
+                    }
+                }
+                return;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll

@@ -109,12 +109,16 @@ struct LoadRowMajorI {   // element(i, k) = p[z*sz + kb*skb + k*ld + i]     (i c
 };
 
 // ---- epilogues ------------------------------------------------------------------------------------------
+template <class E> struct epi_has_pre { static constexpr bool value = false; };
 struct EpiPlain {   // C[z*sz + m*ld + n] ; optional bias per row (m) or per column (n), optional ReLU,
                     // optional residual add (same layout as C), beta (0: overwrite, 1: accumulate)
     float* c; int64_t sz, ld;
     const float* bias_m; const float* bias_n; const float* residual;
     const float* mask;      // optional: result is zeroed where mask[o] <= 0 (ReLU backward of the consumer), non-atomic only
     int relu; int accumulate; int atomic;
+    // optional softmax backward folded into the producer of dP (no split-K): C = scale[o] * (v - rowsub[z*rowsub_sz + m]),
+    // i.e. dS = P * (dP - delta) with delta the per-row sum of P * dP (computed from the outputs, see nl_rowdot_kernel)
+    const float* scale = nullptr; const float* rowsub = nullptr; int64_t rowsub_sz = 0;
     __device__ __forceinline__ void operator()(int z, int m, int n, float v, bool first_split) const {
         int64_t o = z * sz + (int64_t)m * ld + n;
         if (first_split) {
@@ -122,13 +126,26 @@ struct EpiPlain {   // C[z*sz + m*ld + n] ; optional bias per row (m) or per col
             if (bias_n) v += bias_n[n];
             if (residual) v += residual[o];
         }
+        if (scale) v = scale[o] * (v - rowsub[z * rowsub_sz + m]);      // element-wise form; the large-tile kernel batches
         if (atomic) { unsafeAtomicAdd(c + o, v); return; }
         if (accumulate) v += c[o];
         if (relu) v = fmaxf(v, 0.f);
         if (mask && !(mask[o] > 0.f)) v = 0.f;
         c[o] = v;
     }
+    // two-phase form for epilogues that read auxiliary tensors (scale / rowsub): a kernel first collects the operands of a
+    // batch of elements, then stores - a load issued between two stores of `c` cannot be moved ahead of them (possible
+    // alias), so the element-wise form above serialises one memory round trip per element.
+    __device__ __forceinline__ bool wants_pre() const { return scale != nullptr; }
+    __device__ __forceinline__ void pre(int z, int m, int n, float& s, float& d) const {
+        s = scale[z * sz + (int64_t)m * ld + n];
+        d = rowsub[z * rowsub_sz + m];
+    }
+    __device__ __forceinline__ void store_pre(int z, int m, int n, float v, float s, float d) const {
+        c[z * sz + (int64_t)m * ld + n] = s * (v - d);
+    }
 };
+template <> struct epi_has_pre<EpiPlain> { static constexpr bool value = true; };
 
 template <class LA, class LB, class EPI>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmDims d, LA la, LB lb, EPI epi) {

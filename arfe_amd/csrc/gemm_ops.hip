@@ -311,29 +311,25 @@ __global__ __launch_bounds__(256) void nl_softmax_rows_kernel(float* __restrict_
         if (j < L) row[j] = v[i] * inv;
     }
 }
-// dS = P * (dP - sum_j P dP), in place over dP
-__global__ __launch_bounds__(256) void nl_softmax_bwd_rows_kernel(const float* __restrict__ P, float* __restrict__ dP, int L) {
-    const float* prow = P + (int64_t)blockIdx.x * L;
-    float* drow = dP + (int64_t)blockIdx.x * L;
-    float p[NL_ROW_REGS], g[NL_ROW_REGS];
+// delta[z][i] = sum_c a[z][c][i] * b[z][c][i]  ([B, C, L] operands): the row sums sum_j P_ij dP_ij of the softmax backward
+// equal dy_i . y_i (y = P g is the forward output), so they never need the L x L matrices.  64 positions x 4 channel
+// quarters per workgroup.
+__global__ __launch_bounds__(256) void nl_rowdot_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                        float* __restrict__ delta, int C, int L) {
+    __shared__ float red[3][64];
+    const int li = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + li, z = blockIdx.y;
+    const int cq = (C + 3) / 4, c0 = q * cq, c1 = c0 + cq < C ? c0 + cq : C;
     float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < NL_ROW_REGS; ++i) {
-        int j = threadIdx.x + i * 256;
-        p[i] = j < L ? prow[j] : 0.f;
-        g[i] = j < L ? drow[j] : 0.f;
-        s += p[i] * g[i];
+    if (i < L) {
+        const float* pa = a + ((int64_t)z * C + c0) * L + i;
+        const float* pb = b + ((int64_t)z * C + c0) * L + i;
+#pragma unroll 8
+        for (int c = c0; c < c1; ++c) { s += pa[0] * pb[0]; pa += L; pb += L; }
     }
-    __shared__ float red[4];
-    s = wave_sum(s);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    if (q > 0) red[q - 1][li] = s;
     __syncthreads();
-    s = (red[0] + red[1]) + (red[2] + red[3]);
-#pragma unroll
-    for (int i = 0; i < NL_ROW_REGS; ++i) {
-        int j = threadIdx.x + i * 256;
-        if (j < L) drow[j] = p[i] * (g[i] - s);
-    }
+    if (q == 0 && i < L) delta[(int64_t)z * L + i] = ((s + red[0][li]) + red[1][li]) + red[2][li];
 }
 
 __global__ void relu_inplace_kernel(float* __restrict__ x, int64_t n) {
@@ -623,8 +619,8 @@ extern "C" int32_t arfe_conv3x3_bwd_weight(int32_t R, int32_t C, const float* x,
 // NonLocal2D
 // =========================================================================================================
 extern "C" int64_t arfe_nonlocal_workspace_bytes(int32_t B, int32_t C, int32_t L) {
-    // wcat (3C*C) + bcat (3C) + dwcat (3C*C) + dbcat (3C) + dtpg [B,3C,L] + dy [B,C,L]
-    int64_t f = (int64_t)2 * (3 * C * C + 3 * C) + (int64_t)B * 3 * C * L + (int64_t)B * C * L;
+    // wcat (3C*C) + bcat (3C) + dwcat (3C*C) + dbcat (3C) + dtpg [B,3C,L] + dy [B,C,L] + delta [B,L]
+    int64_t f = (int64_t)2 * (3 * C * C + 3 * C) + (int64_t)B * 3 * C * L + (int64_t)B * C * L + (int64_t)B * L;
     return f * (int64_t)sizeof(float) + 256;
 }
 
@@ -701,6 +697,7 @@ extern "C" int32_t arfe_nonlocal_bwd(int32_t B, int32_t C, int32_t L, const floa
     float* dbcat = dwcat + (size_t)3 * C * C;
     float* dtpg = dbcat + (size_t)3 * C;
     float* dy = dtpg + (size_t)B * 3 * CL;
+    float* delta = dy + (size_t)B * CL;
     hipLaunchKernelGGL(nl_pack_kernel, dim3(cdiv(3 * C * C, 256)), dim3(256), 0, st, w_theta, w_phi, w_g,
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, wcat, (float*)nullptr, C);
     ARFE_CHECK_LAUNCH();
@@ -733,10 +730,14 @@ extern "C" int32_t arfe_nonlocal_bwd(int32_t B, int32_t C, int32_t L, const floa
         rc = launch_gemm_auto(C, L, C, 1, B, 1, la, lb, e, st);
         if (rc) return rc;
     }
-    {   // dP[z][i][j] = sum_c dy[c][i] g[c][j]
+    {   // dS[z][i][j] = P[i][j] * (dP[i][j] - delta[i]),  dP[i][j] = sum_c dy[c][i] g[c][j],  delta[i] = sum_j P dP = dy_i . y_i:
+        // the softmax backward rides in the epilogue of the dP contraction, dP itself is never stored
+        hipLaunchKernelGGL(nl_rowdot_kernel, dim3(cdiv(L, 64), B), dim3(256), 0, st, (const float*)dy, y, delta, C, L);
+        ARFE_CHECK_LAUNCH();
         LoadRowMajorI la{dy, CL, 0, L, L, C};
         LoadRowMajorI lb{tpg + 2 * CL, 3 * CL, 0, L, L, C};
         EpiPlain e = epi_plain(dP, LL, L);
+        e.scale = P; e.rowsub = delta; e.rowsub_sz = L;
         rc = launch_gemm_auto(L, L, C, 1, B, 1, la, lb, e, st);
         if (rc) return rc;
     }
@@ -747,8 +748,6 @@ extern "C" int32_t arfe_nonlocal_bwd(int32_t B, int32_t C, int32_t L, const floa
         rc = gemm_autosplit(C, L, L, 1, B, la, lb, e, 0, st);
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(nl_softmax_bwd_rows_kernel, dim3(B * L), dim3(256), 0, st, P, dP, L);   // dP <- dS
-    ARFE_CHECK_LAUNCH();
     {   // dtheta[z][c][i] = sum_j dS[i][j] phi[c][j]
         LoadRowMajorK la{tpg + CL, 3 * CL, 0, L, C, L};
         LoadRowMajorK lb{dP, LL, 0, L, L, L};
