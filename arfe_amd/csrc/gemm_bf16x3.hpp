@@ -850,6 +850,29 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_n224_kernel(GemmDims d, LA
         return;
     }
     // D layout: lane -> column l15, rows 4*lq + r
+    if constexpr (epi_has_rowbias<EPI>::value) {       // the 16 rows' biases first, then nothing but stores
+        float rb[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * 64 + i * 16 + 4 * lq + r;
+                rb[i][r] = epi.row_bias(m < d.M ? m : d.M - 1);
+            }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                const int n = n0 + wn * 112 + j * 16 + l15;
+                if (n >= d.N) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + wm * 64 + i * 16 + 4 * lq + r;
+                    if (m < d.M) epi.store_rb(z, m, n, acc[i][j][r], first_split, rb[i][r]);
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll

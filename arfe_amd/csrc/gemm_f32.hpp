@@ -109,7 +109,14 @@ struct LoadRowMajorI {   // element(i, k) = p[z*sz + kb*skb + k*ld + i]     (i c
 };
 
 // ---- epilogues ------------------------------------------------------------------------------------------
+// Read-only auxiliary operands of an epilogue (bias, residual, masks, scale) are loaded through the constant address
+// space: the compiler may then move those loads ahead of the epilogue's earlier stores.  Through a plain pointer every
+// such load may alias the output and has to wait for the store before it - one memory round trip per output element.
+// (None of these tensors is written by the kernel that reads it; `accumulate` reads the output itself and stays plain.)
+typedef const float __attribute__((address_space(4)))* epi_cptr;
+__device__ __forceinline__ float epi_ld(const float* p, int64_t i) { return ((epi_cptr)(uintptr_t)p)[i]; }
 template <class E> struct epi_has_pre { static constexpr bool value = false; };
+template <class E> struct epi_has_rowbias { static constexpr bool value = false; };
 struct EpiPlain {   // C[z*sz + m*ld + n] ; optional bias per row (m) or per column (n), optional ReLU,
                     // optional residual add (same layout as C), beta (0: overwrite, 1: accumulate)
     float* c; int64_t sz, ld;
@@ -122,15 +129,15 @@ struct EpiPlain {   // C[z*sz + m*ld + n] ; optional bias per row (m) or per col
     __device__ __forceinline__ void operator()(int z, int m, int n, float v, bool first_split) const {
         int64_t o = z * sz + (int64_t)m * ld + n;
         if (first_split) {
-            if (bias_m) v += bias_m[m];
-            if (bias_n) v += bias_n[n];
-            if (residual) v += residual[o];
+            if (bias_m) v += epi_ld(bias_m, m);
+            if (bias_n) v += epi_ld(bias_n, n);
+            if (residual) v += epi_ld(residual, o);
         }
-        if (scale) v = scale[o] * (v - rowsub[z * rowsub_sz + m]);      // element-wise form; the large-tile kernel batches
+        if (scale) v = epi_ld(scale, o) * (v - epi_ld(rowsub, z * rowsub_sz + m));
         if (atomic) { unsafeAtomicAdd(c + o, v); return; }
         if (accumulate) v += c[o];
         if (relu) v = fmaxf(v, 0.f);
-        if (mask && !(mask[o] > 0.f)) v = 0.f;
+        if (mask && !(epi_ld(mask, o) > 0.f)) v = 0.f;
         c[o] = v;
     }
     // two-phase form for epilogues that read auxiliary tensors (scale / rowsub): a kernel first collects the operands of a
@@ -138,8 +145,8 @@ struct EpiPlain {   // C[z*sz + m*ld + n] ; optional bias per row (m) or per col
     // alias), so the element-wise form above serialises one memory round trip per element.
     __device__ __forceinline__ bool wants_pre() const { return scale != nullptr; }
     __device__ __forceinline__ void pre(int z, int m, int n, float& s, float& d) const {
-        s = scale[z * sz + (int64_t)m * ld + n];
-        d = rowsub[z * rowsub_sz + m];
+        s = epi_ld(scale, z * sz + (int64_t)m * ld + n);
+        d = epi_ld(rowsub, z * rowsub_sz + m);
     }
     __device__ __forceinline__ void store_pre(int z, int m, int n, float v, float s, float d) const {
         c[z * sz + (int64_t)m * ld + n] = s * (v - d);

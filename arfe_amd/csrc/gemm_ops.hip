@@ -62,14 +62,21 @@ struct ConvGatherB {   // B(n=(r,p), k=ci) for tap kb: x[r*roi_stride + ci*49 + 
 };
 struct EpiConv {       // y[r*roi_stride + co*49 + p] = act(v + bias[co]) * [mask > 0]
     float* y; int64_t roi_stride; const float* bias; int relu; const float* mask; int64_t mask_roi_stride;
-    __device__ __forceinline__ void operator()(int, int m, int n, float v, bool) const {
+    __device__ __forceinline__ void operator()(int z, int m, int n, float v, bool first) const {
+        store_rb(z, m, n, v, first, row_bias(m));
+    }
+    // the per-row bias can be fetched for all rows of a thread before its first store (a load between two stores of y
+    // waits for the earlier store: possible alias) - see the 256x224 kernel's epilogue
+    __device__ __forceinline__ float row_bias(int m) const { return bias ? epi_ld(bias, m) : 0.f; }
+    __device__ __forceinline__ void store_rb(int, int m, int n, float v, bool, float b) const {
         int r = n / 49, p = n - r * 49;
-        if (bias) v += bias[m];
+        v += b;
         if (relu) v = fmaxf(v, 0.f);
-        if (mask && !(mask[(int64_t)r * mask_roi_stride + m * 49 + p] > 0.f)) v = 0.f;
+        if (mask && !(epi_ld(mask, (int64_t)r * mask_roi_stride + m * 49 + p) > 0.f)) v = 0.f;
         y[(int64_t)r * roi_stride + m * 49 + p] = v;
     }
 };
+template <> struct epi_has_rowbias<EpiConv> { static constexpr bool value = true; };
 
 // Weight gradient of the 3x3 conv: reduction index k' = r*56 + p with the 49 pixels of an RoI padded to 7 octets
 // (p >= 49 is zero), so a k-octet never straddles two RoIs: K' = R*56.
