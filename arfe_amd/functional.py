@@ -18,20 +18,22 @@ class _Probe:
     """Optional HIP-event brackets around single kernel launches (bench.py's live roofline timing).
     Events are recorded on the launch stream (torch's current stream == the stream handed to the C ABI)."""
     enabled = False
+    only = None         # optional set of probe names: the others stay silent (each bracket costs two event records)
     records = {}
 
     def __init__(self, name):
         self.name = name
+        self.on = _Probe.enabled and (_Probe.only is None or name in _Probe.only)
 
     def __enter__(self):
-        if _Probe.enabled:
+        if self.on:
             self.e0 = torch.cuda.Event(enable_timing=True)
             self.e1 = torch.cuda.Event(enable_timing=True)
             self.e0.record(torch.cuda.current_stream())
         return self
 
     def __exit__(self, *exc):
-        if _Probe.enabled:
+        if self.on:
             self.e1.record(torch.cuda.current_stream())
             _Probe.records.setdefault(self.name, []).append((self.e0, self.e1))
         return False
@@ -41,8 +43,9 @@ def probe(name):
     return _Probe(name)
 
 
-def probe_enable(flag=True):
+def probe_enable(flag=True, only=None):
     _Probe.enabled = flag
+    _Probe.only = set(only) if only else None
     _Probe.records = {}
 
 
