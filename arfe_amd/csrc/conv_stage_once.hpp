@@ -1,0 +1,223 @@
+// 3x3 conv on [R, C, 7, 7] RoI tiles, "stage once" form of the implicit GEMM (forward and data gradient):
+//   y[m][n] = sum_{tap, k} W[tap][m][k] * x[k][n + shift(tap)]      n = (RoI, pixel), shift = dy*7 + dx, 0 outside the 7x7
+// The 256x224 GEMM kernel gathers, splits and stores the activation tile once per (tap, channel slice): nine times per
+// slice, and that staging - not the MFMAs - bounds it (tools/probe/mma_probe.hip).  Here a 32-channel slice of x is staged
+// ONCE per workgroup as a [240 pixels][32 ch] hi/lo image (the 224 pixels of the tile + 8 halo pixels each side, because a
+// tile boundary may cut an RoI) and the nine taps read ROW-SHIFTED B fragments from it; a lane whose source pixel is
+// outside the 7x7 map reads a zero row instead (address select, no arithmetic on the data).  Only the pre-split weights are
+// staged per (tap, slice).  Same tile, wave layout, MFMA (v_mfma_f32_16x16x32_bf16) and epilogue as the 256x224 kernel.
+#pragma once
+#include "gemm_bf16x3.hpp"
+
+namespace arfe {
+
+constexpr int CS_BN = 224, CS_HALO = 8, CS_ROWS = CS_BN + 2 * CS_HALO;      // 240 staged pixel rows, row 240 = zeros
+constexpr int CS_BLD = 40;                                                  // B image: 80-byte rows (shifted reads: no swizzle)
+constexpr int CS_A_IMG = XL_BM * XS_LD;                                     // A image (swizzled 64-byte rows), elements
+constexpr int CS_B_IMG = (CS_ROWS + 1) * CS_BLD;
+constexpr int CS_LDS_BYTES = (2 * 2 * CS_A_IMG + 2 * 2 * CS_B_IMG) * 2;     // 2 buffers x (hi, lo) of each operand
+
+struct ConvStageDims { int M, N, C, tiles_n; };
+
+template <class EPI>
+__global__ __launch_bounds__(512, 2) void conv3x3_stage_once_kernel(ConvStageDims d, const float* __restrict__ wsplit,
+                                                                    const float* __restrict__ x, int64_t roi_stride, EPI epi) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short cs_lds[];
+    auto img_a = [&](int buf, int lo) -> unsigned short* { return cs_lds + (buf * 2 + lo) * CS_A_IMG; };
+    auto img_b = [&](int buf, int lo) -> unsigned short* { return cs_lds + 4 * CS_A_IMG + (buf * 2 + lo) * CS_B_IMG; };
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l15 = lane & 15, lq = lane >> 4;
+    const int tn = blockIdx.x, tm = blockIdx.y;
+    const int m0 = tm * XL_BM, n0 = tn * CS_BN;
+    const int nslices = d.C / 32, nsteps = nslices * 9;
+
+    f32x4 acc[4][7];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 7; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // zero rows of the four B images
+    for (int i = tid; i < 4 * CS_BLD; i += 512) (cs_lds + 4 * CS_A_IMG + (i / CS_BLD) * CS_B_IMG + CS_ROWS * CS_BLD)[i % CS_BLD] = 0;
+
+    // ---- A staging (pre-split weight words, k-fast): two octets per thread ----
+    int a_row[2], a_off[2];
+    const float* a_src[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        a_row[i] = (tid >> 2) + 128 * i;
+        const int oct = tid & 3;
+        a_off[i] = a_row[i] * XS_LD + 8 * (oct ^ xs_swz(a_row[i]));
+        const int m = m0 + a_row[i];
+        a_src[i] = wsplit + (int64_t)(m < d.M ? m : d.M - 1) * d.C + 8 * oct;        // + tap*M*C + k0 per step
+    }
+    // ---- B staging (activations, pixel-fast): row = staged pixel, two octets (8 channels each) per thread ----
+    const int b_row = tid & 255;
+    const bool b_on = b_row < CS_ROWS;
+    int b_oct[2];
+    const float* b_src;
+    {
+        int g = n0 - CS_HALO + (b_on ? b_row : 0);
+        g = g < 0 ? 0 : (g >= d.N ? d.N - 1 : g);            // clamped pixels are only ever read through masked lanes
+        const int r = g / 49, p = g - r * 49;
+        b_src = x + (int64_t)r * roi_stride + p;
+        b_oct[0] = tid >> 8; b_oct[1] = (tid >> 8) + 2;
+    }
+    float ra[2][8], rb[2][8];
+    auto fetch_a = [&](int step) {
+        const int tap = step % 9, k0 = (step / 9) * 32;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) ld8_contig(a_src[i] + (int64_t)tap * d.M * d.C + k0, ra[i]);
+    };
+    auto fetch_b = [&](int slice) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float* q = b_src + (int64_t)(slice * 32 + 8 * b_oct[i]) * 49;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) rb[i][j] = q[j * 49];
+        }
+    };
+    auto stash_a = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            bf16x8 hi, lo;
+            unpack8(ra[i], hi, lo);
+            *reinterpret_cast<bf16x8*>(img_a(buf, 0) + a_off[i]) = hi;
+            *reinterpret_cast<bf16x8*>(img_a(buf, 1) + a_off[i]) = lo;
+        }
+    };
+    auto stash_b = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            bf16x8 hi, lo;
+            split8(rb[i], hi, lo);
+            if (b_on) {
+                *reinterpret_cast<bf16x8*>(img_b(buf, 0) + b_row * CS_BLD + 8 * b_oct[i]) = hi;
+                *reinterpret_cast<bf16x8*>(img_b(buf, 1) + b_row * CS_BLD + 8 * b_oct[i]) = lo;
+            }
+        }
+    };
+    // ---- per-lane fragment geometry: column block j of this wave covers tile pixels wn*112 + j*16 + l15 ----
+    int b_base[7];          // element offset of the UNSHIFTED source row (tile pixel + halo) + this lane's k-octet
+    unsigned vm[7];         // bit t: tap t reads inside the 7x7 map
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        const int nl = wn * 112 + j * 16 + l15;
+        b_base[j] = (nl + CS_HALO) * CS_BLD + 8 * lq;
+        int g = n0 + nl;
+        g = g < d.N ? g : d.N - 1;
+        const int p = g % 49, py = p / 7, px = p - py * 7;
+        unsigned m = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
+            m |= ((unsigned)yy < 7u && (unsigned)xx < 7u) ? (1u << t) : 0u;
+        }
+        vm[j] = m;
+    }
+    const int zero_off = CS_ROWS * CS_BLD + 8 * lq;
+    const int frag_oct = 8 * (lq ^ xs_swz(l15));
+    auto mma = [&](int abuf, int bbuf, int tap) {
+        const int sh = ((tap / 3 - 1) * 7 + (tap % 3 - 1)) * CS_BLD;        // wave-uniform row shift, in elements
+        bf16x8 ah[4], al[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int off = (wm * 64 + t * 16 + l15) * XS_LD + frag_oct;
+            ah[t] = *reinterpret_cast<const bf16x8*>(img_a(abuf, 0) + off);
+            al[t] = *reinterpret_cast<const bf16x8*>(img_a(abuf, 1) + off);
+        }
+        bf16x8 bh[2], bl[2];
+        {
+            const int off = ((vm[0] >> tap) & 1u) ? b_base[0] + sh : zero_off;
+            bh[0] = *reinterpret_cast<const bf16x8*>(img_b(bbuf, 0) + off);
+            bl[0] = *reinterpret_cast<const bf16x8*>(img_b(bbuf, 1) + off);
+        }
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            if (j + 1 < 7) {
+                const int off = ((vm[j + 1] >> tap) & 1u) ? b_base[j + 1] + sh : zero_off;
+                bh[(j + 1) & 1] = *reinterpret_cast<const bf16x8*>(img_b(bbuf, 0) + off);
+                bl[(j + 1) & 1] = *reinterpret_cast<const bf16x8*>(img_b(bbuf, 1) + off);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j & 1], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j & 1], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j & 1], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    // ---- pipeline: A double-buffered per step (tap inner), B double-buffered per 9-step slice ----
+    fetch_b(0);
+    fetch_a(0);
+    stash_b(0);
+    stash_a(0);
+    if (nslices > 1) fetch_b(1);
+    if (nsteps > 1) fetch_a(1);
+    __syncthreads();
+    int abuf = 0;
+    for (int s = 0; s < nsteps; ++s) {
+        const int tap = s % 9, slice = s / 9;
+        if (s + 1 < nsteps) stash_a(abuf ^ 1);
+        if (s + 2 < nsteps) fetch_a(s + 2);
+        if (tap == 8 && slice + 1 < nslices) {          // the next slice's activations: held in registers since tap 0
+            stash_b((slice + 1) & 1);
+            if (slice + 2 < nslices) fetch_b(slice + 2);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mma(abuf, slice & 1, tap);
+        __syncthreads();
+        abuf ^= 1;
+    }
+
+    // ---- epilogue: D layout lane -> column l15, rows 4*lq + r (as the 256x224 kernel) ----
+    float rbias[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wm * 64 + i * 16 + 4 * lq + r;
+            rbias[i][r] = epi.row_bias(m < d.M ? m : d.M - 1);
+        }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const int n = n0 + wn * 112 + j * 16 + l15;
+            if (n >= d.N) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * 64 + i * 16 + 4 * lq + r;
+                if (m < d.M) epi.store_rb(0, m, n, acc[i][j][r], true, rbias[i][r]);
+            }
+        }
+}
+
+// -> true when the stage-once kernel ran (shape fits; ARFE_CONV_STAGE_ONCE=0 switches it off), false to use the generic GEMM
+template <class EPI>
+static inline bool launch_conv_stage_once(int R, int C, const float* wsplit, const float* x, int64_t roi_stride, EPI epi,
+                                          hipStream_t stream, int32_t* rc) {
+    static const char* sw = getenv("ARFE_CONV_STAGE_ONCE");
+    *rc = ARFE_OK;
+    const int N = R * 49;
+    if ((sw && sw[0] == '0') || gemm_use_f32() || N % CS_BN != 0 || C % 32 != 0 || C < 64) return false;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)conv3x3_stage_once_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                CS_LDS_BYTES) != hipSuccess) {
+            set_error("conv3x3: cannot reserve %d bytes of LDS", CS_LDS_BYTES);
+            *rc = ARFE_ERR_LAUNCH;
+            return true;
+        }
+        attr = true;
+    }
+    ConvStageDims d{C, N, C, N / CS_BN};
+    hipLaunchKernelGGL((conv3x3_stage_once_kernel<EPI>), dim3(d.tiles_n, cdiv(C, XL_BM)), dim3(512), CS_LDS_BYTES, stream, d,
+                       wsplit, x, roi_stride, epi);
+    if (hipGetLastError() != hipSuccess) { set_error("conv3x3 stage-once launch failed"); *rc = ARFE_ERR_LAUNCH; }
+    return true;
+}
+
+}  // namespace arfe

@@ -77,6 +77,9 @@ struct EpiConv {       // y[r*roi_stride + co*49 + p] = act(v + bias[co]) * [mas
     }
 };
 template <> struct epi_has_rowbias<EpiConv> { static constexpr bool value = true; };
+}  // namespace arfe
+#include "conv_stage_once.hpp"
+namespace arfe {
 
 // Weight gradient of the 3x3 conv: reduction index k' = r*56 + p with the 49 pixels of an RoI padded to 7 octets
 // (p >= 49 is zero), so a k-octet never straddles two RoIs: K' = R*56.
@@ -521,6 +524,10 @@ extern "C" int32_t arfe_conv3x3_fwd(int32_t R, int32_t C, const float* x, int64_
     ConvGatherB lb{x, x_roi_stride, R * 49, C, conv_zeros()};
     ARFE_CHECK_ARG(lb.zeros, ARFE_ERR_LAUNCH, "conv3x3: cannot allocate the padding block");
     EpiConv e{y, y_roi_stride, b, relu, nullptr, 0};
+    {
+        int32_t rc_so;
+        if (launch_conv_stage_once(R, C, wp, x, x_roi_stride, e, as_stream(stream), &rc_so)) return rc_so;
+    }
     return launch_gemm_auto(C, R * 49, C, 9, 1, 1, la, lb, e, as_stream(stream), /*exact=*/false, /*kb_inner=*/true);
 }
 
@@ -535,6 +542,10 @@ extern "C" int32_t arfe_conv3x3_bwd_data(int32_t R, int32_t C, const void* packe
     ConvGatherB lb{dy, dy_roi_stride, R * 49, C, conv_zeros()};
     ARFE_CHECK_ARG(lb.zeros, ARFE_ERR_LAUNCH, "conv3x3: cannot allocate the padding block");
     EpiConv e{dx, dx_roi_stride, nullptr, 0, dx_mask, dx_mask_roi_stride};
+    {
+        int32_t rc_so;
+        if (launch_conv_stage_once(R, C, wd, dy, dy_roi_stride, e, as_stream(stream), &rc_so)) return rc_so;
+    }
     return launch_gemm_auto(C, R * 49, C, 9, 1, 1, la, lb, e, as_stream(stream), /*exact=*/false, /*kb_inner=*/true);
 }
 
