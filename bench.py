@@ -214,7 +214,7 @@ def main():
 
     if rank == 0:
         imgs = world * B * args.steps
-        # dominant kernel: the implicit-GEMM 3x3 conv (gemm_bf16x3_n224_kernel<LoadSplitK, ConvGatherB, EpiConv>),
+        # dominant kernel: the implicit-GEMM 3x3 conv (conv3x3_stage_once_kernel<EpiConv>, conv_stage_once.hpp),
         # 3 forward + 3 data-gradient launches per step, each 2*C*C*9 * R*49 flop
         conv_ms = probes.get('conv3x3_fwd', []) + probes.get('conv3x3_bwd_data', [])
         conv_flop = 2.0 * 256 * 256 * 9 * R * 49
@@ -240,12 +240,13 @@ def main():
                        "per_gpu_batch": B, "global_batch": world * B, "rois_per_gpu": R, "channels": 256,
                        "pyramid": "200x336,100x168,50x84,25x42,13x21", "parallelism": f"image-dp{world}"},
             "roofline": {"bound": "mfma",
-                         "kernel": ("gemm_f32_kernel" if f32_mode else
-                                    "gemm_bf16x3_n224_kernel (256x224 tile) / gemm_bf16x3_large_kernel (256x256)") +
-                                   "<LoadSplitK,ConvGatherB,EpiConv> (3x3 conv 256->256 on [R,256,7,7], fwd + data-grad)",
+                         "kernel": ("gemm_f32_kernel<LoadRowMajorK,ConvGatherB,EpiConv>" if f32_mode else
+                                    "conv3x3_stage_once_kernel<EpiConv> (256x224 tile, bf16x3 MFMA; gemm_bf16x3_* when "
+                                    "R*49 is not a multiple of 224)") +
+                                   " (3x3 conv 256->256 on [R,256,7,7], fwd + data-grad)",
                          "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(ach / peak, 4),
-                         "traffic": None if f32_mode else pmc_traffic(("gemm_bf16x3_", "ConvGatherB")),
+                         "traffic": None if f32_mode else pmc_traffic(("conv3x3_stage_once_kernel",)),
                          "traffic_unit": "bytes/launch (PMC, profiles/r01_pmc_hbm_traffic.json)",
                          "algorithmic_bytes_per_launch": int(2 * R * 256 * 49 * 4 + 9 * 256 * 256 * 4),
                          "mfma_flop_per_algorithmic_flop": 1 if f32_mode else 3,

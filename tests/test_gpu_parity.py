@@ -406,6 +406,34 @@ def test_conv3x3_bench_size_matches_torch_cpu(Fn, dev, R):
     assert relerr(db, br.grad) <= TOL_GRAD
 
 
+@pytest.mark.parametrize('R,C', [(32, 64), (96, 96), (64, 320)])
+def test_conv3x3_stage_once_kernel_matches_torch_cpu(Fn, dev, R, C):
+    """The stage-once conv kernel (conv_stage_once.hpp; taken when R*49 is a multiple of 224, i.e. R a multiple of 32, and
+    C a multiple of 32): 224-pixel tiles cut RoIs, so the 8-pixel halo, the zero row of padding lanes, ReLU + bias, a
+    strided channel-slice input (the wh/hh convs read slices of the [R,3C,7,7] concat) and a second M tile (C = 320) are
+    all exercised; forward and data gradient against torch-CPU fp32 conv2d."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(50 + R)
+    xcat = torch.randn(R, 3 * C, 7, 7, generator=g)
+    w = torch.randn(C, C, 3, 3, generator=g) * 0.05
+    b = torch.randn(C, generator=g) * 0.1
+    dy = torch.randn(R, C, 7, 7, generator=g)
+    xs = xcat[:, C:2 * C].clone().requires_grad_(True)          # the middle slice of the concat
+    wr = w.clone().requires_grad_(True)
+    y_ref = F.relu(F.conv2d(xs, wr, b, padding=1))
+    y_ref.backward(dy)
+    xd, wd, bd, dyd = xcat.to(dev), w.to(dev), b.to(dev), dy.to(dev)
+    pk = Fn.conv3x3_pack_op(wd)
+    y = Fn.conv3x3_fwd_op(xd.data_ptr() + 4 * C * 49, 3 * C * 49, R, C, pk, bd, True)
+    assert relerr(y, y_ref.detach()) <= TOL
+    # data gradient of the un-activated conv (ReLU backward is the producer's job): dx = conv^T(dy * [y > 0])
+    dym = dyd * (y > 0)
+    dx = torch.full_like(xd, float('nan'))
+    Fn.conv3x3_bwd_data_op(R, C, pk, dym.contiguous(), dx.data_ptr() + 4 * C * 49, 3 * C * 49)
+    assert relerr(dx[:, C:2 * C], xs.grad) <= TOL_GRAD
+    assert torch.isnan(dx[:, :C]).all() and torch.isnan(dx[:, 2 * C:]).all()      # neighbouring slices untouched
+
+
 def _run_fpn(dev, xs_cpu, params_cpu, num_outs, cots_cpu):
     import arfe_amd
     in_channels = [x.shape[1] for x in xs_cpu]
