@@ -1,0 +1,237 @@
+// Weight gradient of the 3x3 conv on [R, C, 7, 7] RoI tiles, "stage once" form:
+//   dWp[tap][co][ci] = sum_{r, py, px} dy[r][co][py][px] * x[r][ci][py + dy(tap)][px + dx(tap)]        (0 outside the 7x7)
+// The generic path runs nine GEMMs (one per tap) that each gather, split and store BOTH operands again; that staging, not
+// the MFMAs, bounds it.  Here a workgroup owns a 128 (co) x 64 (ci) block of ALL NINE taps (9 x 4 accumulator blocks per
+// wave) over a slice of the pixel rows, and per K-step of four pixel rows (k-octet = one row of 7 pixels + a zero slot):
+//   * dy rows are staged once: [128 co][4 octets];
+//   * x rows once with a one-row halo, in THREE column-shifted copies made in registers before the split
+//     (dx = -1, 0, +1; zeros shifted in): [3][64 ci][6 octets].  A tap's row shift dy is then a whole k-octet
+//     (octet lq + dy + 1 of copy dx + 1) and a lane whose shifted row leaves the RoI reads a zero octet.
+// Partial sums of the row slices are added atomically into the zeroed dWp (as the generic path does).
+#pragma once
+#include "gemm_bf16x3.hpp"
+
+namespace arfe {
+
+constexpr int WS_CO = 128, WS_CI = 64;
+constexpr int WS_A_LD = 32;                         // dy image row: 4 octets (64 B), swizzled like the GEMM images
+constexpr int WS_B_LD = 48;                         // x image row: 6 octets (96 B)
+constexpr int WS_A_IMG = WS_CO * WS_A_LD;           // elements per (hi | lo) image
+constexpr int WS_B_IMG = WS_CI * WS_B_LD;           // per dx copy and (hi | lo)
+constexpr int WS_BUF = 2 * WS_A_IMG + 6 * WS_B_IMG; // one buffer: A hi, A lo, B[3][hi, lo]
+constexpr int WS_LDS_BYTES = (2 * WS_BUF + 8) * 2;  // two buffers + one zero octet
+
+struct WgradStageDims { int R, C, rows_total, rows_per_slice, tiles_ci; };
+
+__global__ __launch_bounds__(512, 2) void conv3x3_wgrad_stage_once_kernel(WgradStageDims d, const float* __restrict__ x,
+                                                                          int64_t x_roi_stride, const float* __restrict__ dy,
+                                                                          int64_t dy_roi_stride, float* __restrict__ dwp) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short ws_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l15 = lane & 15, lq = lane >> 4;
+    const int co0 = ((int)blockIdx.x / d.tiles_ci) * WS_CO, ci0 = ((int)blockIdx.x % d.tiles_ci) * WS_CI;
+    const int row_begin = blockIdx.y * d.rows_per_slice;
+    int row_end = row_begin + d.rows_per_slice;
+    if (row_end > d.rows_total) row_end = d.rows_total;
+    if (row_begin >= row_end) return;
+    const int nsteps = (row_end - row_begin + 3) >> 2;
+    auto img_a = [&](int buf, int lo) -> unsigned short* { return ws_lds + buf * WS_BUF + lo * WS_A_IMG; };
+    auto img_b = [&](int buf, int dxi, int lo) -> unsigned short* {
+        return ws_lds + buf * WS_BUF + 2 * WS_A_IMG + (dxi * 2 + lo) * WS_B_IMG;
+    };
+    unsigned short* zero_oct = ws_lds + 2 * WS_BUF;
+    if (tid < 8) zero_oct[tid] = 0;
+
+    f32x4 acc[9][2][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- staging maps ----
+    // the pixel row a thread stages is WAVE-UNIFORM (dy: waves 2q, 2q+1 take octet q of the 128 channels; x: wave o takes
+    // octet o of the 64 channels), so the row's RoI / py arithmetic, its validity and the "row 6" window shift are scalar
+    // work and uniform branches instead of per-lane selects
+    const int a_co = tid & 127, a_q = __builtin_amdgcn_readfirstlane(tid >> 7);
+    const int a_off = a_co * WS_A_LD + 8 * (a_q ^ xs_swz(a_co));
+    const bool b_on = tid < WS_CI * 6;
+    const int b_ci = tid & 63, b_o = __builtin_amdgcn_readfirstlane(b_on ? tid >> 6 : 0);   // x: octet o = row (first row - 1 + o)
+    const int b_off = b_ci * WS_B_LD + 8 * b_o;
+    float ra[8], rb[8];
+    auto fetch = [&](int step) {
+        const int g0 = row_begin + 4 * step;
+        {
+            const int g = g0 + a_q;
+            const bool ok = g < row_end;
+            const int gc = ok ? g : row_end - 1;
+            const int r = gc / 7, py = gc - r * 7;
+            // rows 0..5: the 8-float window starts at the row; row 6: read pixels 41..48 and shift by one so that the
+            // window never leaves the channel's 49 floats
+            const float* q = dy + (int64_t)r * dy_roi_stride + (co0 + a_co) * 49 + (py < 6 ? py * 7 : 41);
+            float t[8];
+            ld8_contig(q, t);
+            if (!ok) {
+#pragma unroll
+                for (int j = 0; j < 7; ++j) ra[j] = 0.f;
+            } else if (py < 6) {
+#pragma unroll
+                for (int j = 0; j < 7; ++j) ra[j] = t[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 7; ++j) ra[j] = t[j + 1];
+            }
+            ra[7] = 0.f;
+        }
+        if (b_on) {
+            const int g = g0 - 1 + b_o;
+            const bool ok = g >= row_begin - 1 && g >= 0 && g < d.rows_total;
+            const int gc = g < 0 ? 0 : (g >= d.rows_total ? d.rows_total - 1 : g);
+            const int r = gc / 7, py = gc - r * 7;
+            const float* q = x + (int64_t)r * x_roi_stride + (ci0 + b_ci) * 49 + (py < 6 ? py * 7 : 41);
+            float t[8];
+            ld8_contig(q, t);
+            if (!ok) {
+#pragma unroll
+                for (int j = 0; j < 7; ++j) rb[j] = 0.f;
+            } else if (py < 6) {
+#pragma unroll
+                for (int j = 0; j < 7; ++j) rb[j] = t[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 7; ++j) rb[j] = t[j + 1];
+            }
+            rb[7] = 0.f;
+        }
+    };
+    auto stash = [&](int buf) {
+        bf16x8 hi, lo;
+        split8(ra, hi, lo);
+        *reinterpret_cast<bf16x8*>(img_a(buf, 0) + a_off) = hi;
+        *reinterpret_cast<bf16x8*>(img_a(buf, 1) + a_off) = lo;
+        if (b_on) {
+            // three column-shifted copies: slot px of copy dx holds x[px + dx] (0 where px + dx leaves the row; slot 7 = 0)
+            const float vm1[8] = {0.f, rb[0], rb[1], rb[2], rb[3], rb[4], rb[5], 0.f};
+            const float vp1[8] = {rb[1], rb[2], rb[3], rb[4], rb[5], rb[6], 0.f, 0.f};
+            split8(vm1, hi, lo);
+            *reinterpret_cast<bf16x8*>(img_b(buf, 0, 0) + b_off) = hi;
+            *reinterpret_cast<bf16x8*>(img_b(buf, 0, 1) + b_off) = lo;
+            split8(rb, hi, lo);
+            *reinterpret_cast<bf16x8*>(img_b(buf, 1, 0) + b_off) = hi;
+            *reinterpret_cast<bf16x8*>(img_b(buf, 1, 1) + b_off) = lo;
+            split8(vp1, hi, lo);
+            *reinterpret_cast<bf16x8*>(img_b(buf, 2, 0) + b_off) = hi;
+            *reinterpret_cast<bf16x8*>(img_b(buf, 2, 1) + b_off) = lo;
+        }
+    };
+    // ---- fragment geometry ----
+    const int a_frag = 8 * (lq ^ xs_swz(l15));           // A rows: wm*32 + i*16 + l15 (bases are multiples of 16)
+    auto mma = [&](int buf, int step) {
+        // this lane's k-octet is pixel row g = row_begin + 4*step + lq: a tap with dy is valid when py + dy stays in [0, 7)
+        const int g = row_begin + 4 * step + lq;
+        const int py = g % 7;
+        bf16x8 ah[2], al[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int off = (wm * 32 + i * 16 + l15) * WS_A_LD + a_frag;
+            ah[i] = *reinterpret_cast<const bf16x8*>(img_a(buf, 0) + off);
+            al[i] = *reinterpret_cast<const bf16x8*>(img_a(buf, 1) + off);
+        }
+        // B fragments of tap t + 1 are read before the twelve MFMAs of tap t are issued (register double buffer)
+        bf16x8 bh[2][2], bl[2][2];
+        auto read_b = [&](int t, int slot) {
+            const int dyy = t / 3 - 1, dxi = t % 3;
+            const bool ok = (unsigned)(py + dyy) < 7u;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int off = (wn * 32 + j * 16 + l15) * WS_B_LD + 8 * (lq + dyy + 1);
+                const unsigned short* ph = ok ? img_b(buf, dxi, 0) + off : zero_oct;
+                const unsigned short* pl = ok ? img_b(buf, dxi, 1) + off : zero_oct;
+                bh[slot][j] = *reinterpret_cast<const bf16x8*>(ph);
+                bl[slot][j] = *reinterpret_cast<const bf16x8*>(pl);
+            }
+        };
+        read_b(0, 0);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            if (t + 1 < 9) read_b(t + 1, (t + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[t & 1][j], acc[t][i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[t & 1][j], acc[t][i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[t & 1][j], acc[t][i][j], 0, 0, 0);
+        }
+    };
+
+    fetch(0);
+    stash(0);
+    if (nsteps > 1) fetch(1);
+    __syncthreads();
+    int buf = 0;
+    for (int s = 0; s < nsteps; ++s) {
+        if (s + 1 < nsteps) stash(buf ^ 1);
+        if (s + 2 < nsteps) fetch(s + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(buf, s);
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    // ---- epilogue: D layout lane -> column l15 (ci), rows 4*lq + r (co) ----
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = ci0 + wn * 32 + j * 16 + l15;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = co0 + wm * 32 + i * 16 + 4 * lq + r;
+                    unsafeAtomicAdd(dwp + ((int64_t)t * d.C + m) * d.C + n, acc[t][i][j][r]);
+                }
+            }
+}
+
+// -> true when the kernel ran (C a multiple of 128, bf16x3 mode, ARFE_CONV_STAGE_ONCE != 0); dwp must be zeroed before
+static inline bool launch_conv_wgrad_stage_once(int R, int C, const float* x, int64_t x_roi_stride, const float* dy,
+                                                int64_t dy_roi_stride, float* dwp, hipStream_t stream, int32_t* rc) {
+    static const char* sw = getenv("ARFE_CONV_STAGE_ONCE");
+    *rc = ARFE_OK;
+    if ((sw && sw[0] == '0') || gemm_use_f32() || C % WS_CO != 0 || R < 64) return false;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)conv3x3_wgrad_stage_once_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                WS_LDS_BYTES) != hipSuccess) {
+            set_error("conv3x3 wgrad: cannot reserve %d bytes of LDS", WS_LDS_BYTES);
+            *rc = ARFE_ERR_LAUNCH;
+            return true;
+        }
+        attr = true;
+    }
+    WgradStageDims d;
+    d.R = R; d.C = C; d.rows_total = R * 7; d.tiles_ci = C / WS_CI;
+    const int tiles = (C / WS_CO) * d.tiles_ci;
+    int nslices = 256 / tiles;
+    if (nslices < 1) nslices = 1;
+    d.rows_per_slice = ((cdiv(d.rows_total, nslices) + 3) / 4) * 4;
+    nslices = cdiv(d.rows_total, d.rows_per_slice);
+    hipLaunchKernelGGL(conv3x3_wgrad_stage_once_kernel, dim3(tiles, nslices), dim3(512), WS_LDS_BYTES, stream, d, x, x_roi_stride,
+                       dy, dy_roi_stride, dwp);
+    if (hipGetLastError() != hipSuccess) { set_error("conv3x3 wgrad stage-once launch failed"); *rc = ARFE_ERR_LAUNCH; }
+    return true;
+}
+
+}  // namespace arfe

@@ -79,6 +79,7 @@ struct EpiConv {       // y[r*roi_stride + co*49 + p] = act(v + bias[co]) * [mas
 template <> struct epi_has_rowbias<EpiConv> { static constexpr bool value = true; };
 }  // namespace arfe
 #include "conv_stage_once.hpp"
+#include "conv_wgrad_stage_once.hpp"
 namespace arfe {
 
 // Weight gradient of the 3x3 conv: reduction index k' = r*56 + p with the 49 pixels of an RoI padded to 7 octets
@@ -581,7 +582,9 @@ extern "C" int32_t arfe_conv3x3_bwd_weight(int32_t R, int32_t C, const float* x,
     EpiPlain e = epi_plain(dwp, (int64_t)C * C, C);
     e.atomic = 1;
     int32_t rc;
-    if (zvar) {
+    if (launch_conv_wgrad_stage_once(R, C, x, x_roi_stride, dy, dy_roi_stride, dwp, st, &rc)) {
+        // (the nine taps in one kernel, operands staged once per pixel chunk: conv_wgrad_stage_once.hpp)
+    } else if (zvar) {
         GemmDims zv;
         const int tiles = cdiv(C, XL_BM) * cdiv(C, XL_BN);
         const int total_steps = 3 * steps7 + 6 * steps6;
