@@ -434,6 +434,29 @@ def test_conv3x3_stage_once_kernel_matches_torch_cpu(Fn, dev, R, C):
     assert torch.isnan(dx[:, :C]).all() and torch.isnan(dx[:, 2 * C:]).all()      # neighbouring slices untouched
 
 
+@pytest.mark.parametrize('R,C', [(64, 128), (65, 128), (200, 256)])
+def test_conv3x3_wgrad_stage_once_kernel_matches_torch_cpu(Fn, dev, R, C):
+    """The stage-once weight-gradient kernel (conv_wgrad_stage_once.hpp; C a multiple of 128, R >= 64): row slices of a
+    single K-step, a last slice that ends inside a K-step (R = 65: 455 pixel rows), the row halo across slice and RoI
+    boundaries, the three column-shifted copies, and a strided x slice of the [R,3C,7,7] concat; dw and db against
+    torch-CPU fp32 conv2d."""
+    import torch.nn.functional as F
+    from arfe_amd import hip
+    g = torch.Generator().manual_seed(70 + R)
+    xcat = torch.randn(R, 3 * C, 7, 7, generator=g)
+    w = torch.randn(C, C, 3, 3, generator=g) * 0.05
+    b = torch.zeros(C)
+    dy = torch.randn(R, C, 7, 7, generator=g)
+    xs = xcat[:, 2 * C:].clone()
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    F.conv2d(xs, wr, br, padding=1).backward(dy)
+    xd, wd, dyd = xcat.to(dev), w.to(dev), dy.to(dev)
+    ws = torch.empty(int(hip.lib().arfe_conv3x3_workspace_bytes(C)), dtype=torch.uint8, device=dev)
+    dw, db = Fn.conv3x3_bwd_weight_op(xd.data_ptr() + 4 * 2 * C * 49, 3 * C * 49, R, C, wd, dyd, ws)
+    assert relerr(dw, wr.grad) <= TOL_GRAD
+    assert relerr(db, br.grad) <= TOL_GRAD
+
+
 def _run_fpn(dev, xs_cpu, params_cpu, num_outs, cots_cpu):
     import arfe_amd
     in_channels = [x.shape[1] for x in xs_cpu]
