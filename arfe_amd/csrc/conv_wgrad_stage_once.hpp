@@ -29,8 +29,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_stage_once_kernel(WgradS
     extern __shared__ __attribute__((aligned(16))) unsigned short ws_lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, l15 = lane & 15, lq = lane >> 4;
-    const int co0 = ((int)blockIdx.x / d.tiles_ci) * WS_CO, ci0 = ((int)blockIdx.x % d.tiles_ci) * WS_CI;
-    const int row_begin = blockIdx.y * d.rows_per_slice;
+    // grid = (row slices, output blocks): workgroups go round-robin to the 8 XCDs by their linear id, so with the slice as
+    // the fast index the eight output blocks of one row slice share an XCD and its L2 serves their common dy / x rows
+    const int co0 = ((int)blockIdx.y / d.tiles_ci) * WS_CO, ci0 = ((int)blockIdx.y % d.tiles_ci) * WS_CI;
+    const int row_begin = blockIdx.x * d.rows_per_slice;
     int row_end = row_begin + d.rows_per_slice;
     if (row_end > d.rows_total) row_end = d.rows_total;
     if (row_begin >= row_end) return;
@@ -228,7 +230,7 @@ static inline bool launch_conv_wgrad_stage_once(int R, int C, const float* x, in
     if (nslices < 1) nslices = 1;
     d.rows_per_slice = ((cdiv(d.rows_total, nslices) + 3) / 4) * 4;
     nslices = cdiv(d.rows_total, d.rows_per_slice);
-    hipLaunchKernelGGL(conv3x3_wgrad_stage_once_kernel, dim3(tiles, nslices), dim3(512), WS_LDS_BYTES, stream, d, x, x_roi_stride,
+    hipLaunchKernelGGL(conv3x3_wgrad_stage_once_kernel, dim3(nslices, tiles), dim3(512), WS_LDS_BYTES, stream, d, x, x_roi_stride,
                        dy, dy_roi_stride, dwp);
     if (hipGetLastError() != hipSuccess) { set_error("conv3x3 wgrad stage-once launch failed"); *rc = ARFE_ERR_LAUNCH; }
     return true;
