@@ -784,3 +784,19 @@ def test_shape_sweep_in_exact_fp32_mode():
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert out.stdout.count('case ') == 5
+
+
+def test_generic_conv_kernels_with_stage_once_switched_off():
+    """ARFE_CONV_STAGE_ONCE=0 (read once per process) routes the 3x3 convs through the generic implicit-GEMM kernels, which
+    remain the path for RoI counts that are not a multiple of 32 and channel counts that are not a multiple of 128: the
+    bench-size conv cases must pass there too (fresh process)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, ARFE_CONV_STAGE_ONCE='0')
+    out = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(ROOT, 'tests', 'test_gpu_parity.py'), '-q', '-x', '-m', 'gpu',
+                          '-k', 'conv3x3_bench_size or rff_head_golden'], env=env, cwd=ROOT, capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert ' passed' in out.stdout
