@@ -195,14 +195,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stage_once_kernel(ConvStageDim
         }
 }
 
-// -> true when the stage-once kernel ran (shape fits; ARFE_CONV_STAGE_ONCE=0 switches it off), false to use the generic GEMM
+// -> true when the stage-once kernel ran (C a multiple of 32, at least one full tile of pixels; ARFE_CONV_STAGE_ONCE=0
+// switches it off), false to use the generic GEMM
 template <class EPI>
 static inline bool launch_conv_stage_once(int R, int C, const float* wsplit, const float* x, int64_t roi_stride, EPI epi,
                                           hipStream_t stream, int32_t* rc) {
     static const char* sw = getenv("ARFE_CONV_STAGE_ONCE");
     *rc = ARFE_OK;
     const int N = R * 49;
-    if ((sw && sw[0] == '0') || gemm_use_f32() || N % CS_BN != 0 || C % 32 != 0 || C < 64) return false;
+    if ((sw && sw[0] == '0') || gemm_use_f32() || N < CS_BN || C % 32 != 0 || C < 64) return false;
     static bool attr = false;
     if (!attr) {
         if (hipFuncSetAttribute((const void*)conv3x3_stage_once_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -213,7 +214,7 @@ static inline bool launch_conv_stage_once(int R, int C, const float* wsplit, con
         }
         attr = true;
     }
-    ConvStageDims d{C, N, C, N / CS_BN};
+    ConvStageDims d{C, N, C, cdiv(N, CS_BN)};      // a ragged last tile: clamped loads, columns >= N are never stored
     hipLaunchKernelGGL((conv3x3_stage_once_kernel<EPI>), dim3(d.tiles_n, cdiv(C, XL_BM)), dim3(512), CS_LDS_BYTES, stream, d,
                        wsplit, x, roi_stride, epi);
     if (hipGetLastError() != hipSuccess) { set_error("conv3x3 stage-once launch failed"); *rc = ARFE_ERR_LAUNCH; }

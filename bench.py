@@ -241,8 +241,7 @@ def main():
                        "pyramid": "200x336,100x168,50x84,25x42,13x21", "parallelism": f"image-dp{world}"},
             "roofline": {"bound": "mfma",
                          "kernel": ("gemm_f32_kernel<LoadRowMajorK,ConvGatherB,EpiConv>" if f32_mode else
-                                    "conv3x3_stage_once_kernel<EpiConv> (256x224 tile, bf16x3 MFMA; gemm_bf16x3_* when "
-                                    "R*49 is not a multiple of 224)") +
+                                    "conv3x3_stage_once_kernel<EpiConv> (256x224 tile, bf16x3 MFMA)") +
                                    " (3x3 conv 256->256 on [R,256,7,7], fwd + data-grad)",
                          "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(ach / peak, 4),

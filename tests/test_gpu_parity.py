@@ -406,10 +406,10 @@ def test_conv3x3_bench_size_matches_torch_cpu(Fn, dev, R):
     assert relerr(db, br.grad) <= TOL_GRAD
 
 
-@pytest.mark.parametrize('R,C', [(32, 64), (96, 96), (64, 320)])
+@pytest.mark.parametrize('R,C', [(32, 64), (96, 96), (64, 320), (50, 64), (5, 96)])
 def test_conv3x3_stage_once_kernel_matches_torch_cpu(Fn, dev, R, C):
-    """The stage-once conv kernel (conv_stage_once.hpp; taken when R*49 is a multiple of 224, i.e. R a multiple of 32, and
-    C a multiple of 32): 224-pixel tiles cut RoIs, so the 8-pixel halo, the zero row of padding lanes, ReLU + bias, a
+    """The stage-once conv kernel (conv_stage_once.hpp; taken when R*49 >= 224 and C is a multiple of 32, a ragged last
+    tile included: R = 50 and R = 5): 224-pixel tiles cut RoIs, so the 8-pixel halo, the zero row of padding lanes, ReLU + bias, a
     strided channel-slice input (the wh/hh convs read slices of the [R,3C,7,7] concat) and a second M tile (C = 320) are
     all exercised; forward and data gradient against torch-CPU fp32 conv2d."""
     import torch.nn.functional as F
