@@ -19,7 +19,9 @@ constexpr int WS_B_LD = 48;                         // x image row: 6 octets (96
 constexpr int WS_A_IMG = WS_CO * WS_A_LD;           // elements per (hi | lo) image
 constexpr int WS_B_IMG = WS_CI * WS_B_LD;           // per dx copy and (hi | lo)
 constexpr int WS_BUF = 2 * WS_A_IMG + 6 * WS_B_IMG; // one buffer: A hi, A lo, B[3][hi, lo]
-constexpr int WS_LDS_BYTES = (2 * WS_BUF + 8) * 2;  // two buffers + one zero octet
+constexpr int WS_ZERO = WS_B_IMG + 16 * WS_B_LD + 8; // zero region: a lane that selects it reads (hi, lo) x (j = 0, 1) at the same
+                                                     // constant offsets as from an image
+constexpr int WS_LDS_BYTES = (2 * WS_BUF + WS_ZERO) * 2;
 
 struct WgradStageDims { int R, C, rows_total, rows_per_slice, tiles_ci; };
 
@@ -41,8 +43,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_stage_once_kernel(WgradS
     auto img_b = [&](int buf, int dxi, int lo) -> unsigned short* {
         return ws_lds + buf * WS_BUF + 2 * WS_A_IMG + (dxi * 2 + lo) * WS_B_IMG;
     };
-    unsigned short* zero_oct = ws_lds + 2 * WS_BUF;
-    if (tid < 8) zero_oct[tid] = 0;
+    unsigned short* zero_base = ws_lds + 2 * WS_BUF;
+    for (int i = tid; i < WS_ZERO; i += 512) zero_base[i] = 0;
 
     f32x4 acc[9][2][2];
 #pragma unroll
@@ -129,6 +131,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_stage_once_kernel(WgradS
     };
     // ---- fragment geometry ----
     const int a_frag = 8 * (lq ^ xs_swz(l15));           // A rows: wm*32 + i*16 + l15 (bases are multiples of 16)
+    const int b_frag = (wn * 32 + l15) * WS_B_LD + 8 * lq;  // B rows: wn*32 + j*16 + l15, octet lq + dy + 1
     auto mma = [&](int buf, int step) {
         // this lane's k-octet is pixel row g = row_begin + 4*step + lq: a tap with dy is valid when py + dy stays in [0, 7)
         const int g = row_begin + 4 * step + lq;
@@ -145,13 +148,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_stage_once_kernel(WgradS
         auto read_b = [&](int t, int slot) {
             const int dyy = t / 3 - 1, dxi = t % 3;
             const bool ok = (unsigned)(py + dyy) < 7u;
+            // ONE address select per tap: hi / lo and the two column blocks sit at constant offsets from it (ds_read
+            // immediates), in an image as in the zero region
+            const unsigned short* p = ok ? img_b(buf, dxi, 0) + b_frag + 8 * (dyy + 1) : zero_base;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int off = (wn * 32 + j * 16 + l15) * WS_B_LD + 8 * (lq + dyy + 1);
-                const unsigned short* ph = ok ? img_b(buf, dxi, 0) + off : zero_oct;
-                const unsigned short* pl = ok ? img_b(buf, dxi, 1) + off : zero_oct;
-                bh[slot][j] = *reinterpret_cast<const bf16x8*>(ph);
-                bl[slot][j] = *reinterpret_cast<const bf16x8*>(pl);
+                bh[slot][j] = *reinterpret_cast<const bf16x8*>(p + j * 16 * WS_B_LD);
+                bl[slot][j] = *reinterpret_cast<const bf16x8*>(p + WS_B_IMG + j * 16 * WS_B_LD);
             }
         };
         read_b(0, 0);
