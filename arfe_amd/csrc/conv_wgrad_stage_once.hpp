@@ -115,18 +115,27 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_stage_once_kernel(WgradS
         *reinterpret_cast<bf16x8*>(img_a(buf, 0) + a_off) = hi;
         *reinterpret_cast<bf16x8*>(img_a(buf, 1) + a_off) = lo;
         if (b_on) {
-            // three column-shifted copies: slot px of copy dx holds x[px + dx] (0 where px + dx leaves the row; slot 7 = 0)
-            const float vm1[8] = {0.f, rb[0], rb[1], rb[2], rb[3], rb[4], rb[5], 0.f};
-            const float vp1[8] = {rb[1], rb[2], rb[3], rb[4], rb[5], rb[6], 0.f, 0.f};
-            split8(vm1, hi, lo);
-            *reinterpret_cast<bf16x8*>(img_b(buf, 0, 0) + b_off) = hi;
-            *reinterpret_cast<bf16x8*>(img_b(buf, 0, 1) + b_off) = lo;
+            // three column-shifted copies: slot px of copy dx holds x[px + dx] (0 where px + dx leaves the row; slot 7 = 0).
+            // The split is element-wise, so the row is split ONCE and the packed bf16 words are shifted (v_alignbit):
+            // copy -1 = {0, e0..e5, 0}, copy +1 = {e1..e6, 0, 0}.
             split8(rb, hi, lo);
             *reinterpret_cast<bf16x8*>(img_b(buf, 1, 0) + b_off) = hi;
             *reinterpret_cast<bf16x8*>(img_b(buf, 1, 1) + b_off) = lo;
-            split8(vp1, hi, lo);
-            *reinterpret_cast<bf16x8*>(img_b(buf, 2, 0) + b_off) = hi;
-            *reinterpret_cast<bf16x8*>(img_b(buf, 2, 1) + b_off) = lo;
+            auto shifted = [&](const bf16x8& v, bf16x8& m1, bf16x8& p1) {
+                const u32x4 w = __builtin_bit_cast(u32x4, v);
+                const unsigned t1 = __builtin_amdgcn_alignbit(w[1], w[0], 16), t2 = __builtin_amdgcn_alignbit(w[2], w[1], 16),
+                               t3 = __builtin_amdgcn_alignbit(w[3], w[2], 16);
+                const u32x4 a = {w[0] << 16, t1, t2, w[2] >> 16}, b = {t1, t2, t3, 0u};
+                m1 = __builtin_bit_cast(bf16x8, a);
+                p1 = __builtin_bit_cast(bf16x8, b);
+            };
+            bf16x8 hm, hp, lm, lp;
+            shifted(hi, hm, hp);
+            shifted(lo, lm, lp);
+            *reinterpret_cast<bf16x8*>(img_b(buf, 0, 0) + b_off) = hm;
+            *reinterpret_cast<bf16x8*>(img_b(buf, 0, 1) + b_off) = lm;
+            *reinterpret_cast<bf16x8*>(img_b(buf, 2, 0) + b_off) = hp;
+            *reinterpret_cast<bf16x8*>(img_b(buf, 2, 1) + b_off) = lp;
         }
     };
     // ---- fragment geometry ----
