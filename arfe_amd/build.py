@@ -22,6 +22,16 @@ CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
 LDFLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc"]
 
 
+def sources_sha():
+    """sha256 over the kernel sources and headers: profiles record it, bench.py quotes PMC traffic only when it matches."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(SOURCES + HEADERS):
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def _mtime(path):
     return os.path.getmtime(path) if os.path.exists(path) else 0.0
 

@@ -43,12 +43,10 @@ int32_t zero_buffers(const ZeroList& z, hipStream_t stream) {
 }
 
 bool gemm_use_f32() {
-    static int cached = -1;           // process-level switch, read once: ARFE_GEMM_F32=1 -> exact-fp32 MFMA
-    if (cached < 0) {
-        const char* e = getenv("ARFE_GEMM_F32");
-        cached = (e && e[0] == '1') ? 1 : 0;
-    }
-    return cached == 1;
+    // process-level switch, read once (a function-local static is initialised under the C++11 guard, so the main and
+    // the autograd thread may both arrive first): ARFE_GEMM_F32=1 -> exact-fp32 MFMA
+    static const bool on = []() { const char* e = getenv("ARFE_GEMM_F32"); return e && e[0] == '1'; }();
+    return on;
 }
 
 int32_t check_pyramid(const arfe_pyramid_t* p) {

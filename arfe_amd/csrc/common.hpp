@@ -5,6 +5,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
+
 #include "../../include/arfe_hip.h"
 
 namespace arfe {
@@ -119,6 +121,22 @@ int32_t zero_buffers(const ZeroList& z, hipStream_t stream);
 // dwp[tap][co][ci] -> dw[co][ci][tap] (gemm_ops.hip)
 int32_t conv3x3_unpermute_dw(int C, const float* dwp, float* dw, hipStream_t stream);
 bool gemm_use_f32();
+
+// Function attributes (the opt-in to >64 KB of dynamic LDS) and small constant blocks belong to ONE device: a process
+// that drives several GPUs must repeat them per device.  DeviceOnce is a flag per device ordinal; two threads racing
+// on the same device both run the (idempotent) body.
+constexpr int ARFE_MAX_DEVICES = 64;
+struct DeviceOnce {
+    std::atomic<unsigned char> done[ARFE_MAX_DEVICES];
+    template <class F> bool run(F&& body) {          // body() -> bool ok
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= ARFE_MAX_DEVICES) return body();
+        if (done[dev].load(std::memory_order_acquire)) return true;
+        if (!body()) return false;
+        done[dev].store(1, std::memory_order_release);
+        return true;
+    }
+};
 
 template <int N>
 struct PtrArray { const float* p[N]; };

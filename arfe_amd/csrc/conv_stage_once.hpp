@@ -204,15 +204,12 @@ static inline bool launch_conv_stage_once(int R, int C, const float* wsplit, con
     *rc = ARFE_OK;
     const int N = R * 49;
     if ((sw && sw[0] == '0') || gemm_use_f32() || N < CS_BN || C % 32 != 0 || C < 64) return false;
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute((const void*)conv3x3_stage_once_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                CS_LDS_BYTES) != hipSuccess) {
-            set_error("conv3x3: cannot reserve %d bytes of LDS", CS_LDS_BYTES);
-            *rc = ARFE_ERR_LAUNCH;
-            return true;
-        }
-        attr = true;
+    static DeviceOnce attr;           // per instantiation and per device
+    if (!attr.run([]() { return hipFuncSetAttribute((const void*)conv3x3_stage_once_kernel<EPI>,
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, CS_LDS_BYTES) == hipSuccess; })) {
+        set_error("conv3x3: cannot reserve %d bytes of LDS", CS_LDS_BYTES);
+        *rc = ARFE_ERR_LAUNCH;
+        return true;
     }
     ConvStageDims d{C, N, C, cdiv(N, CS_BN)};      // a ragged last tile: clamped loads, columns >= N are never stored
     hipLaunchKernelGGL((conv3x3_stage_once_kernel<EPI>), dim3(d.tiles_n, cdiv(C, XL_BM)), dim3(512), CS_LDS_BYTES, stream, d,

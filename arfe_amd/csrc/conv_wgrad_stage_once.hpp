@@ -225,15 +225,12 @@ static inline bool launch_conv_wgrad_stage_once(int R, int C, const float* x, in
     static const char* sw = getenv("ARFE_CONV_STAGE_ONCE");
     *rc = ARFE_OK;
     if ((sw && sw[0] == '0') || gemm_use_f32() || C % WS_CO != 0 || R < 64) return false;
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute((const void*)conv3x3_wgrad_stage_once_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                WS_LDS_BYTES) != hipSuccess) {
-            set_error("conv3x3 wgrad: cannot reserve %d bytes of LDS", WS_LDS_BYTES);
-            *rc = ARFE_ERR_LAUNCH;
-            return true;
-        }
-        attr = true;
+    static DeviceOnce attr;
+    if (!attr.run([]() { return hipFuncSetAttribute((const void*)conv3x3_wgrad_stage_once_kernel,
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES) == hipSuccess; })) {
+        set_error("conv3x3 wgrad: cannot reserve %d bytes of LDS", WS_LDS_BYTES);
+        *rc = ARFE_ERR_LAUNCH;
+        return true;
     }
     WgradStageDims d;
     d.R = R; d.C = C; d.rows_total = R * 7; d.tiles_ci = C / WS_CI;

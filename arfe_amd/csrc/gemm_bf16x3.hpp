@@ -970,14 +970,11 @@ static inline int32_t launch_gemm_auto(int M, int N, int K, int kb_count, int ba
             splitk = splitk_large;
             d.splitk = splitk;
             d.tiles_m = cdiv(M, XL_BM); d.tiles_n = N / XN_BN;
-            static bool attr224 = false;
-            if (!attr224) {
-                if (hipFuncSetAttribute((const void*)gemm_bf16x3_n224_kernel<LA, LB, EPI>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, XN_LDS_BYTES) != hipSuccess) {
-                    set_error("gemm: cannot reserve %d bytes of LDS", XN_LDS_BYTES);
-                    return ARFE_ERR_LAUNCH;
-                }
-                attr224 = true;
+            static DeviceOnce attr224;     // per instantiation and per device
+            if (!attr224.run([]() { return hipFuncSetAttribute((const void*)gemm_bf16x3_n224_kernel<LA, LB, EPI>,
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, XN_LDS_BYTES) == hipSuccess; })) {
+                set_error("gemm: cannot reserve %d bytes of LDS", XN_LDS_BYTES);
+                return ARFE_ERR_LAUNCH;
             }
             dim3 grid(d.tiles_m * d.tiles_n, splitk, batch);
             hipLaunchKernelGGL((gemm_bf16x3_n224_kernel<LA, LB, EPI>), grid, dim3(512), XN_LDS_BYTES, stream, d, la, lb, epi);
@@ -1004,14 +1001,11 @@ static inline int32_t launch_gemm_auto(int M, int N, int K, int kb_count, int ba
             batch = 1;                                                     // gridDim.z: the batch is decoded from y
         }
         d.tiles_m = cdiv(M, XL_BM); d.tiles_n = cdiv(N, XL_BN);
-        static bool attr_set = false;      // per instantiation: opt in to the full 160 KB of LDS once
-        if (!attr_set) {
-            if (hipFuncSetAttribute((const void*)gemm_bf16x3_large_kernel<LA, LB, EPI>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, XL_LDS_BYTES) != hipSuccess) {
-                set_error("gemm: cannot reserve %d bytes of LDS", XL_LDS_BYTES);
-                return ARFE_ERR_LAUNCH;
-            }
-            attr_set = true;
+        static DeviceOnce attr_set;        // per instantiation and per device: opt in to the full 160 KB of LDS once
+        if (!attr_set.run([]() { return hipFuncSetAttribute((const void*)gemm_bf16x3_large_kernel<LA, LB, EPI>,
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, XL_LDS_BYTES) == hipSuccess; })) {
+            set_error("gemm: cannot reserve %d bytes of LDS", XL_LDS_BYTES);
+            return ARFE_ERR_LAUNCH;
         }
         dim3 grid(d.tiles_m * d.tiles_n, splitk, batch);
         hipLaunchKernelGGL((gemm_bf16x3_large_kernel<LA, LB, EPI>), grid, dim3(512), XL_LDS_BYTES, stream, d, la, lb, epi);

@@ -1,5 +1,6 @@
 // Dense contractions of the AR path on the exact-fp32 MFMA GEMM (gemm_f32.hpp):
 //   NonLocal2D refine fwd/bwd, AR-RFF 3x3 convs (implicit GEMM) fwd/bwd, nn.Linear fwd/bwd.
+#include <mutex>
 #include <algorithm>
 #include "gemm_bf16x3.hpp"
 
@@ -385,15 +386,24 @@ int32_t conv3x3_unpermute_dw(int C, const float* dwp, float* dw, hipStream_t str
     return ARFE_OK;
 }
 
-// 8*49 zero floats, allocated once per process (the padding taps of ConvGatherB point here)
+// 8*49 zero floats per device, allocated on the first conv of that device (the padding taps of ConvGatherB point here).
+// Filled by a blocking copy from pageable host memory: it has completed when hipMemcpy returns, so the block is valid
+// for whichever stream launches first (a hipMemset on the null stream is not ordered against torch's non-blocking
+// side stream, which is where the first conv of a step runs).
 static const float* conv_zeros() {
-    static const float* z = []() -> const float* {
+    static std::mutex mu;
+    static const float* blocks[ARFE_MAX_DEVICES] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= ARFE_MAX_DEVICES) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!blocks[dev]) {
+        static const float host_zeros[8 * 49] = {};
         float* p = nullptr;
-        if (hipMalloc(&p, sizeof(float) * 8 * 49) != hipSuccess) return nullptr;
-        if (hipMemset(p, 0, sizeof(float) * 8 * 49) != hipSuccess) return nullptr;
-        return p;
-    }();
-    return z;
+        if (hipMalloc(&p, sizeof(host_zeros)) != hipSuccess) return nullptr;
+        if (hipMemcpy(p, host_zeros, sizeof(host_zeros), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(p); return nullptr; }
+        blocks[dev] = p;
+    }
+    return blocks[dev];
 }
 
 }  // namespace arfe

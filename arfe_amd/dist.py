@@ -3,31 +3,70 @@ the only exchange per step is an all-reduce(sum)/world of the parameter gradient
 reference hands to MMDistributedDataParallel (mmdet/apis/train.py:124-128) and allreduce_grads
 (mmdet/core/utils/dist_utils.py:9-41).
 
-Gradients are reduced from ONE flat fp32 bucket per module group (the AR-RFF head's 64 MB, the AR-FPN's 1.1 MB):
+Gradients are reduced from ONE flat bucket per module group and dtype (the AR-RFF head's 64 MB, the AR-FPN's 1.1 MB):
 each parameter's .grad is a view into the bucket, so no flatten/unflatten copies happen in the step, and the
 head's bucket is put on the wire as soon as the head's backward node has produced it, while the neck's backward
-is still running (the collectives run on RCCL's own stream)."""
+is still running (the collectives run on RCCL's own stream).
+
+The view is an optimisation, not an assumption: `optimizer.zero_grad()` (set_to_none=True is torch's default) or any
+`p.grad = None` detaches a parameter from its bucket and autograd then installs a fresh tensor.  Every hook therefore
+checks that the gradient it was called for still lives in its slice and, if not, copies it there and re-points
+`p.grad`; `synchronize()` re-checks every parameter (and zero-fills the slice of one that received no gradient) before
+it waits, so what goes on the wire is always this step's gradient.  Contract: one backward per `synchronize()`."""
 import torch
 import torch.distributed as dist
 
 
 class GradBucket:
+    """One flat buffer in the parameters' dtype (half parameters after wrap_fp16_model get a half bucket)."""
+
     def __init__(self, params):
-        self.params = [p for p in params if p.requires_grad]
+        self.params = list(params)
+        dt = self.params[0].dtype
+        assert all(p.dtype == dt for p in self.params), "a bucket holds one dtype"
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
-        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.flat = torch.zeros(n, dtype=dt, device=dev)
+        self.views = []
         off = 0
         for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
+        self.index = {id(p): i for i, p in enumerate(self.params)}
+        self.fired = [False] * len(self.params)
+        self.pending = len(self.params)
         self.work = None
+        for i in range(len(self.params)):
+            self.attach(i, keep=False)
+
+    def aliased(self, i):
+        g = self.params[i].grad
+        v = self.views[i]
+        return g is not None and g.data_ptr() == v.data_ptr() and g.dtype == v.dtype and g.is_contiguous()
+
+    def attach(self, i, keep):
+        """Make params[i].grad the bucket view; keep=True carries a foreign gradient's values over."""
+        p, v = self.params[i], self.views[i]
+        if self.aliased(i):
+            return
+        with torch.no_grad():
+            if keep and p.grad is not None:
+                v.copy_(p.grad)
+            elif keep:
+                v.zero_()
+        p.grad = v
 
     def zero(self):
         self.flat.zero_()
+        for i in range(len(self.params)):
+            self.attach(i, keep=False)
+
+    def reset(self):
+        self.fired = [False] * len(self.params)
+        self.pending = len(self.params)
 
     def launch(self, world):
-        if world > 1:
+        if world > 1 and self.work is None:
             self.work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=True)
 
     def finish(self, world):
@@ -37,8 +76,15 @@ class GradBucket:
             self.flat.div_(world)
 
 
+def _split_by_dtype(params):
+    groups = {}
+    for p in params:
+        groups.setdefault(p.dtype, []).append(p)
+    return list(groups.values())
+
+
 class GradAllReducer:
-    """buckets: list of parameter lists, in the order their gradients become ready during backward.
+    """param_groups: list of parameter lists, in the order their gradients become ready during backward.
     With a single process there is nothing to exchange: no buckets are created and autograd hands each
     parameter its freshly produced gradient tensor (no accumulate-into-view pass)."""
 
@@ -47,17 +93,23 @@ class GradAllReducer:
         self.param_groups = [[p for p in g if p.requires_grad] for g in param_groups]
         self.buckets = []
         if self.world > 1:
-            self.buckets = [GradBucket(list(g)) for g in self.param_groups]
-            self._pending = [0] * len(self.buckets)
-            for bi, b in enumerate(self.buckets):
+            for g in self.param_groups:
+                self.buckets += [GradBucket(sub) for sub in _split_by_dtype(g)]
+            for b in self.buckets:
                 for p in b.params:
-                    p.register_post_accumulate_grad_hook(self._make_hook(bi))
+                    p.register_post_accumulate_grad_hook(self._make_hook(b))
 
-    def _make_hook(self, bi):
+    def _make_hook(self, b):
         def hook(param):
-            self._pending[bi] -= 1
-            if self._pending[bi] == 0:
-                self.buckets[bi].launch(self.world)
+            i = b.index[id(param)]
+            if b.fired[i]:
+                raise RuntimeError("GradAllReducer: a second backward reached a parameter before synchronize(); "
+                                   "call synchronize() after every backward")
+            b.attach(i, keep=True)          # zero_grad(set_to_none=True) / p.grad=None: adopt the fresh tensor
+            b.fired[i] = True
+            b.pending -= 1
+            if b.pending == 0:
+                b.launch(self.world)
         return hook
 
     def zero_grad(self):
@@ -66,13 +118,22 @@ class GradAllReducer:
                 for p in g:
                     p.grad = None
             return
-        for bi, b in enumerate(self.buckets):
+        for b in self.buckets:
+            assert b.work is None, "zero_grad() while an all-reduce is in flight; call synchronize() first"
             b.zero()
-            self._pending[bi] = len(b.params)
+            b.reset()
 
     def synchronize(self):
         """Call after backward: waits for every bucket's all-reduce and divides by the world size."""
         for b in self.buckets:
-            if b.work is None and self.world > 1:
-                b.launch(self.world)     # bucket not completed by the hooks (e.g. frozen branch): reduce it now
+            if b.work is None:
+                # bucket not completed by the hooks (frozen branch, unused parameter): a parameter without a
+                # gradient this step contributes zeros, never a stale slice; then reduce now so ranks stay in lockstep
+                for i in range(len(b.params)):
+                    if not b.fired[i]:
+                        if b.params[i].grad is None:
+                            b.views[i].zero_()
+                        b.attach(i, keep=True)
+                b.launch(self.world)
             b.finish(self.world)
+            b.reset()

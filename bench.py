@@ -44,20 +44,29 @@ def path_roofline(batch, rois_per_img, step_s):
 
 
 def pmc_traffic(kernel_substr):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE doubled as
-    the gfx950 note in MI355X_MICROARCH.md prescribes, + WRITE_SIZE; tools/pmc_run.sh + tools/pmc_traffic.py on this
-    same bench command).  None when the profile file is absent."""
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_traffic.json')
-    if not os.path.exists(path):
-        return None
+    """(HBM bytes per launch, source note) of the dominant kernel from the newest committed rocprofv3 PMC passes
+    (FETCH_SIZE doubled as the gfx950 note in MI355X_MICROARCH.md prescribes, + WRITE_SIZE; tools/pmc_run.sh +
+    tools/pmc_traffic.py on this same bench command).  PMC passes cannot run inside this process, so the figure is
+    quoted from the committed profile and ONLY while the profile was taken on the kernel sources this run uses
+    (`_meta.csrc_sha` == arfe_amd.build.sources_sha()); otherwise traffic is null and the note says why."""
+    import glob
+    from arfe_amd.build import sources_sha
+    paths = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_hbm_traffic.json')))
+    if not paths:
+        return None, "no committed PMC profile"
+    path = paths[-1]
+    name = os.path.relpath(path, ROOT)
     try:
         d = json.load(open(path))
-        for k, v in d.items():
+        meta = d.get("_meta", {})
+        if meta.get("csrc_sha") != sources_sha():
+            return None, f"{name} was measured on other kernel sources (csrc sha {meta.get('csrc_sha')}): not quoted"
+        for k, v in d["kernels"].items():
             if all(t in k for t in kernel_substr):
-                return v["hbm_bytes_per_launch"]
-    except Exception:
-        return None
-    return None
+                return v["hbm_bytes_per_launch"], f"bytes/launch, PMC passes in {name} (csrc sha {meta['csrc_sha']})"
+    except Exception as e:      # a malformed profile must not take the bench line down
+        return None, f"{name}: {type(e).__name__}"
+    return None, f"{name} has no such kernel"
 
 
 def parse():
@@ -227,6 +236,8 @@ def main():
         nl_ms = (sum(stage_probes.get('nonlocal_fwd', [])) + sum(stage_probes.get('nonlocal_bwd', []))) / stage_steps
         f32_mode = os.environ.get('ARFE_GEMM_F32', '0') == '1'
         peak = PEAK_F32_MFMA_TFLOPS if f32_mode else PEAK_BF16_MFMA_TFLOPS
+        traffic, traffic_note = (None, "exact-fp32 mode: not profiled") if f32_mode else \
+            pmc_traffic(("conv3x3_stage_once_kernel",))
         out = {
             "metric": "imgs/s AR-FPN+AR-RFF fwd+bwd, 5-level 256-ch pyramid @1333x800",
             "value": round(imgs / elapsed, 3), "unit": "imgs/s", "n_gpus": world, "steps": args.steps,
@@ -245,8 +256,7 @@ def main():
                                    " (3x3 conv 256->256 on [R,256,7,7], fwd + data-grad)",
                          "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(ach / peak, 4),
-                         "traffic": None if f32_mode else pmc_traffic(("conv3x3_stage_once_kernel",)),
-                         "traffic_unit": "bytes/launch (PMC, profiles/r01_pmc_hbm_traffic.json)",
+                         "traffic": traffic, "traffic_unit": traffic_note,
                          "algorithmic_bytes_per_launch": int(2 * R * 256 * 49 * 4 + 9 * 256 * 256 * 4),
                          "mfma_flop_per_algorithmic_flop": 1 if f32_mode else 3,
                          "frac_of_exact_fp32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 4),

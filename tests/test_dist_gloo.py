@@ -46,6 +46,50 @@ def _worker(rank, world, port, q):
         ok &= all(p.grad.abs().max() == 0 for p in frozen.parameters())
         # grads are views of the flat bucket (no flatten copies)
         ok &= head.weight.grad.data_ptr() == red.buckets[0].flat.data_ptr()
+    # the default optimizer.zero_grad() (set_to_none=True) drops the bucket views: the reducer must adopt the fresh
+    # gradient tensors autograd installs, and a parameter left without a gradient must contribute zeros
+    opt = torch.optim.SGD(list(head.parameters()) + list(neck.parameters()) + list(frozen.parameters()), lr=0.0)
+    for step in range(3):
+        opt.zero_grad()
+        assert head.weight.grad is None
+        if step == 2:
+            neck.weight.grad = torch.full_like(neck.weight, 7.0)     # a foreign tensor that backward accumulates into
+        x = torch.full((2, 4), float(rank + 2 + step))
+        head(torch.cat([neck(x), x[:, :2]], 1)).sum().backward()
+        red.synchronize()
+        exp = []
+        for r in range(world):
+            h2, n2 = torch.nn.Linear(6, 4), torch.nn.Linear(4, 4)
+            h2.load_state_dict(head.state_dict()); n2.load_state_dict(neck.state_dict())
+            xr = torch.full((2, 4), float(r + 2 + step))
+            h2(torch.cat([n2(xr), xr[:, :2]], 1)).sum().backward()
+            if step == 2:
+                n2.weight.grad += 7.0
+            exp.append([p.grad.clone() for p in list(h2.parameters()) + list(n2.parameters())])
+        mean = [sum(e[i] for e in exp) / world for i in range(len(exp[0]))]
+        got = [p.grad for p in list(head.parameters()) + list(neck.parameters())]
+        ok &= all(torch.allclose(g, m, atol=1e-6) for g, m in zip(got, mean))
+        ok &= all(p.grad is not None and p.grad.abs().max() == 0 for p in frozen.parameters())
+        ok &= head.weight.grad.data_ptr() == red.buckets[0].flat.data_ptr()      # re-attached to the bucket
+    # a second backward before synchronize() is refused instead of silently double-averaging
+    red.zero_grad()
+    head(torch.ones(2, 6)).sum().backward()
+    try:
+        head(torch.ones(2, 6)).sum().backward()
+        ok = False
+    except RuntimeError:
+        pass
+    red.synchronize()
+    # half parameters (wrap_fp16_model) get a half bucket; a mixed group is split per dtype
+    mixed = [torch.nn.Parameter(torch.ones(3, dtype=torch.float16)), torch.nn.Parameter(torch.ones(2)),
+             torch.nn.Parameter(torch.ones(4, dtype=torch.float16))]
+    red2 = GradAllReducer([mixed])
+    ok &= sorted(str(b.flat.dtype) for b in red2.buckets) == ['torch.float16', 'torch.float32']
+    red2.zero_grad()
+    sum((p.float() * (rank + 1)).sum() for p in mixed).backward()
+    red2.synchronize()
+    ok &= all(p.grad.dtype == p.dtype and torch.allclose(p.grad.float(), torch.full_like(p, 1.5, dtype=torch.float32))
+              for p in mixed)
     # max-over-ranks timing reduction used by bench.py
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -786,6 +786,21 @@ def test_shape_sweep_in_exact_fp32_mode():
     assert out.stdout.count('case ') == 5
 
 
+def test_shape_sweep_in_default_bf16x3_mode():
+    """The same sweep through the kernels that SHIP (bf16x3 contractions, generic tiles for these channel counts and
+    RoI counts that are not multiples of 32): their tails and indexing are exercised here, not only by the exact-fp32
+    run above.  Bound 5e-3 L2 (measured <= 4e-3, conv bias gradients of the two widest cases: ReLU-kink flips)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ('ARFE_GEMM_F32', 'ARFE_CONV_STAGE_ONCE', 'ARFE_GEMM_PLAN')}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'fuzz_shapes.py'), '--l2', '5e-3'], env=env, cwd=ROOT,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert out.stdout.count('case ') == 5
+
+
 def test_generic_conv_kernels_with_stage_once_switched_off():
     """ARFE_CONV_STAGE_ONCE=0 (read once per process) routes the 3x3 convs through the generic implicit-GEMM kernels, which
     remain the path for RoI counts that are not a multiple of 32 and channel counts that are not a multiple of 128: the

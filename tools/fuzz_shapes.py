@@ -1,6 +1,9 @@
 """robustness sweep: the whole path (neck -> 3-RoI extractor -> head, fwd+bwd) on unusual shapes against the oracle.
-Reports max-norm and L2 relative errors per configuration; exits non-zero on a mismatch beyond 2e-3 (L2)."""
+Reports max-norm and L2 relative errors per configuration; exits non-zero on a mismatch beyond the L2 bound
+(2e-3, the exact-fp32 mode's; `--l2 5e-3` for the default bf16x3 kernels, whose extra error on the widest cases is
+ReLU-kink flips in the conv bias gradients)."""
 import sys
+TOL = float(sys.argv[sys.argv.index('--l2') + 1]) if '--l2' in sys.argv else 2e-3
 import torch
 sys.path.insert(0, '.')
 import arfe_amd
@@ -88,4 +91,4 @@ for ci, (B, C, fc, sizes, R, r) in enumerate(CASES):
     print(f'case {ci}: B={B} C={C} R={R} refine={r}: worst L2 {wl2:.2e} ({wname}), worst max-norm {wmax:.2e}', flush=True)
     worst = max(worst, wl2)
 print('worst L2', worst)
-sys.exit(0 if worst <= 2e-3 else 1)
+sys.exit(0 if worst <= TOL else 1)

@@ -1,5 +1,7 @@
 #!/bin/bash
-# rocprofv3 PMC passes (no trace domains mixed in, as the pool requires); run on the GPU box from the repo root:
+# rocprofv3 PMC pass: counters + --kernel-trace only (the kernel trace names the dispatches; the pool refuses --pmc
+# together with sys/runtime/hip/hsa/memory-copy/scratch/marker tracing, none of which is used); the program follows
+# `--` directly (python3, no env/bash hop).  Run on the GPU box from the repo root:
 #   bash tools/pmc_run.sh <outdir-under-gpurun_out> "<counter list>" <python script + args>
 set -e
 R=${GRAFT_REPO_ROOT:-$(pwd)}
