@@ -6,12 +6,9 @@ namespace arfe {
 
 // ---- get_adaptive_scale_rois(rois, 1) — same fp32 operation order as additional.py:38-71 -----------------
 // contraction is switched off so no mul+add pair is fused into an fma (the reference rounds every op).
-__global__ void rff_make_rois_kernel(int R, const float* __restrict__ rois, float* __restrict__ h_rois,
-                                     float* __restrict__ w_rois) {
+__device__ __forceinline__ void make_rois_one(const float* __restrict__ roi, float* __restrict__ h, float* __restrict__ w) {
 #pragma clang fp contract(off)
-    int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= R) return;
-    const float b = rois[5 * k], x1 = rois[5 * k + 1], y1 = rois[5 * k + 2], x2 = rois[5 * k + 3], y2 = rois[5 * k + 4];
+    const float b = roi[0], x1 = roi[1], y1 = roi[2], x2 = roi[3], y2 = roi[4];
     const float cx = (x1 + x2) * 0.5f, cy = (y1 + y2) * 0.5f;
     const float rw = x2 - x1 + 1.0f, rh = y2 - y1 + 1.0f;
     const float facs = 1.0f;
@@ -19,8 +16,6 @@ __global__ void rff_make_rois_kernel(int R, const float* __restrict__ rois, floa
     const float w_rate = (rh / rw) * facs + 1.0f;
     const float large_h = rh * h_rate, large_w = rw * w_rate;
     const float lo = 0.1f;   // torch.ones_like(rw) * 0.1 == fp32(0.1)
-    float* h = h_rois + 5 * k;
-    float* w = w_rois + 5 * k;
     h[0] = b;
     h[1] = fmaxf(cx - rw * 0.5f, lo);
     h[2] = fmaxf(cy - large_h * 0.5f, lo);
@@ -32,24 +27,48 @@ __global__ void rff_make_rois_kernel(int R, const float* __restrict__ rois, floa
     w[3] = cx + large_w * 0.5f;
     w[4] = cy + large_h * 0.5f;
 }
+__global__ void rff_make_rois_kernel(int R, const float* __restrict__ rois, float* __restrict__ h_rois,
+                                     float* __restrict__ w_rois) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= R) return;
+    make_rois_one(rois + 5 * k, h_rois + 5 * k, w_rois + 5 * k);
+}
 
 // ---- map_roi_levels: floor(log2(v)) evaluated as "how many of torch's fp32 step points has v reached" -----
 // v = sqrt(w*h)/finest + 1e-6 with IEEE sqrt/div/add in fp32 (hipcc's defaults are correctly rounded).
 // Step points of torch-CPU floor(log2(.)): 2, 4, pred(8), pred(16)  (oracle/arfe_oracle.py LEVEL_STEPS_F32).
-__global__ void map_roi_levels_kernel(int R, const float* __restrict__ rois, int num_levels, float finest,
-                                      int64_t* __restrict__ levels) {
+__device__ __forceinline__ int64_t map_level_one(const float* __restrict__ roi, int num_levels, float finest) {
 #pragma clang fp contract(off)
-    int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= R) return;
-    const float w = rois[5 * k + 3] - rois[5 * k + 1];
-    const float h = rois[5 * k + 4] - rois[5 * k + 2];
+    const float w = roi[3] - roi[1];
+    const float h = roi[4] - roi[2];
     const float scale = __fsqrt_rn(w * h);
     const float v = __fdiv_rn(scale, finest) + 1e-6f;
     const float s3 = __uint_as_float(0x40FFFFFFu);   // largest fp32 below 8
     const float s4 = __uint_as_float(0x417FFFFFu);   // largest fp32 below 16
     int lvl = (v >= 2.0f) + (v >= 4.0f) + (v >= s3) + (v >= s4);   // NaN (negative area) compares false -> 0
     if (lvl > num_levels - 1) lvl = num_levels - 1;
-    levels[k] = (int64_t)lvl;
+    return (int64_t)lvl;
+}
+__global__ void map_roi_levels_kernel(int R, const float* __restrict__ rois, int num_levels, float finest,
+                                      int64_t* __restrict__ levels) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= R) return;
+    levels[k] = map_level_one(rois + 5 * k, num_levels, finest);
+}
+// the AR-RFF glue in one launch: both enlarged RoI sets and the level of all three sets (the enlarged RoIs are read
+// back from the values just stored, i.e. exactly the fp32 numbers the two-call form sees)
+__global__ void rff_roi_sets_kernel(int R, const float* __restrict__ rois, int num_levels, float finest,
+                                    float* __restrict__ h_rois, float* __restrict__ w_rois, int64_t* __restrict__ lv_ori,
+                                    int64_t* __restrict__ lv_w, int64_t* __restrict__ lv_h) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= R) return;
+    float h[5], w[5];
+    make_rois_one(rois + 5 * k, h, w);
+#pragma unroll
+    for (int e = 0; e < 5; ++e) { h_rois[5 * k + e] = h[e]; w_rois[5 * k + e] = w[e]; }
+    lv_ori[k] = map_level_one(rois + 5 * k, num_levels, finest);
+    lv_w[k] = map_level_one(w, num_levels, finest);
+    lv_h[k] = map_level_one(h, num_levels, finest);
 }
 
 // ---- RoIAlign v2 -----------------------------------------------------------------------------------------
@@ -701,6 +720,18 @@ extern "C" int32_t arfe_map_roi_levels(int32_t R, const float* rois, int32_t num
     return ARFE_OK;
 }
 
+extern "C" int32_t arfe_rff_roi_sets(int32_t R, const float* rois, int32_t num_levels, float finest_scale, float* h_rois,
+                                     float* w_rois, int64_t* levels_ori, int64_t* levels_w, int64_t* levels_h, void* stream) {
+    ARFE_CHECK_ARG(R >= 0 && num_levels >= 1 && num_levels <= 5 && finest_scale > 0.f, ARFE_ERR_ARG,
+                   "rff_roi_sets: bad arguments (num_levels=%d)", num_levels);
+    if (R == 0) return ARFE_OK;
+    ARFE_CHECK_ARG(rois && h_rois && w_rois && levels_ori && levels_w && levels_h, ARFE_ERR_ARG, "rff_roi_sets: null pointer");
+    hipLaunchKernelGGL(rff_roi_sets_kernel, dim3(cdiv(R, 256)), dim3(256), 0, as_stream(stream), R, rois, num_levels,
+                       finest_scale, h_rois, w_rois, levels_ori, levels_w, levels_h);
+    ARFE_CHECK_LAUNCH();
+    return ARFE_OK;
+}
+
 extern "C" int64_t arfe_roialign_fwd_workspace_bytes(int32_t nsets, int32_t R) {
     if (nsets < 1 || nsets > RB_MAXSETS || R < 0) return -1;
     return (int64_t)nsets * R * ((int64_t)sizeof(RoiWeightHdr) + (int64_t)2 * 7 * RW_EXT * sizeof(float) + 8) + 64;
@@ -775,10 +806,86 @@ extern "C" int64_t arfe_roialign_bwd_workspace_bytes(const arfe_pyramid_t* pyr, 
            (int64_t)nsets * R * ((int64_t)sizeof(RoiWeightHdr) + (int64_t)2 * 7 * RW_EXT * sizeof(float)) + 64;
 }
 
-extern "C" int32_t arfe_roialign_bwd(const arfe_pyramid_t* pyr, float* const* dfeats, const int32_t* strides,
-                                     int32_t nsets, int32_t R, const float* const* rois, const int64_t* const* levels,
-                                     int32_t pooled, int32_t sample_num, const float* gout, int64_t gout_roi_stride,
-                                     void* workspace, void* stream) {
+namespace {
+struct RoiBwdPlan {
+    RoiTileTable T;
+    int ntiles, mx, nroi;
+    int *counts, *offsets, *cursors, *list, *lmeta;
+    RoiWeightHdr* hdr;
+    float* wtab;
+};
+RoiBwdPlan plan_roi_bwd(const arfe_pyramid_t* pyr, int nsets, int R, void* workspace) {
+    RoiBwdPlan p;
+    p.T = make_roi_tile_table(pyr, &p.ntiles, &p.mx);
+    p.nroi = nsets * R;
+    p.counts = (int*)workspace;
+    p.offsets = p.counts + p.ntiles;
+    p.cursors = p.offsets + p.ntiles + 1;
+    p.list = p.cursors + p.ntiles;
+    p.lmeta = p.list + (size_t)p.nroi * p.mx;
+    uintptr_t after = (uintptr_t)(p.lmeta + (size_t)p.nroi * p.mx);
+    after = (after + 15) & ~(uintptr_t)15;
+    p.hdr = (RoiWeightHdr*)after;
+    p.wtab = (float*)(p.hdr + p.nroi);
+    return p;
+}
+int32_t fill_roi_sets(RoiSets& S, int nsets, int R, const float* const* rois, const int64_t* const* levels, const char* who) {
+    S.nsets = nsets; S.R = R;
+    for (int i = 0; i < RB_MAXSETS; ++i) { S.rois[i] = nullptr; S.levels[i] = nullptr; }
+    for (int i = 0; i < nsets && R > 0; ++i) {
+        ARFE_CHECK_ARG(rois[i] && levels[i], ARFE_ERR_ARG, "%s: null RoI set %d", who, i);
+        S.rois[i] = rois[i]; S.levels[i] = levels[i];
+    }
+    return ARFE_OK;
+}
+}  // namespace
+
+// Everything of the backward that depends on the RoIs alone (tile lists, per-RoI weight tables): a caller can run it
+// beside the forward RoIAlign, on another stream, and hand the filled workspace to arfe_roialign_bwd_prepared later.
+extern "C" int32_t arfe_roialign_bwd_prepare(const arfe_pyramid_t* pyr, const int32_t* strides, int32_t nsets, int32_t R,
+                                             const float* const* rois, const int64_t* const* levels, int32_t pooled,
+                                             int32_t sample_num, void* workspace, void* stream) {
+    int32_t rc = check_pyramid(pyr);
+    if (rc) return rc;
+    ARFE_CHECK_ARG(R >= 0 && nsets >= 1 && nsets <= RB_MAXSETS && sample_num >= 0, ARFE_ERR_ARG, "roialign_bwd: bad arguments");
+    ARFE_CHECK_ARG(pooled == 7, ARFE_ERR_ARG, "roialign_bwd: only 7x7 pooling has a kernel (got %d)", pooled);
+    ARFE_CHECK_ARG(strides && workspace && (R == 0 || (rois && levels)), ARFE_ERR_ARG, "roialign_bwd: null pointer");
+    RoiLevels L;
+    ARFE_CHECK_ARG(fill_roi_levels(L, pyr, nullptr, nullptr, strides) == ARFE_OK, ARFE_ERR_ARG, "roialign_bwd: bad level table");
+    RoiSets S;
+    rc = fill_roi_sets(S, nsets, R, rois, levels, "roialign_bwd");
+    if (rc) return rc;
+    RoiBwdPlan p = plan_roi_bwd(pyr, nsets, R, workspace);
+    hipStream_t st = as_stream(stream);
+    {   // the tile counters
+        ZeroList z;
+        z.add(p.counts, p.ntiles);
+        rc = zero_buffers(z, st);
+        if (rc) return rc;
+    }
+    if (p.nroi > 0) {
+        hipLaunchKernelGGL((roi_bin_kernel<false>), dim3(cdiv(p.nroi, 256)), dim3(256), 0, st, L, S, p.T, pooled, p.counts,
+                           (const int*)p.offsets, p.cursors, p.list, (const RoiWeightHdr*)nullptr, (int*)nullptr);
+        ARFE_CHECK_LAUNCH();
+        hipLaunchKernelGGL(roi_weight_table_kernel, dim3(p.nroi), dim3(256), 0, st, L, S, pooled, sample_num, p.hdr, p.wtab,
+                           (const int32_t*)nullptr, 1);
+        ARFE_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(roi_bin_scan_kernel, dim3(1), dim3(1024), 0, st, (const int*)p.counts, p.offsets, p.cursors, p.ntiles);
+    ARFE_CHECK_LAUNCH();
+    if (p.nroi > 0) {
+        hipLaunchKernelGGL((roi_bin_kernel<true>), dim3(cdiv(p.nroi, 256)), dim3(256), 0, st, L, S, p.T, pooled, p.counts,
+                           (const int*)p.offsets, p.cursors, p.list, (const RoiWeightHdr*)p.hdr, p.lmeta);
+        ARFE_CHECK_LAUNCH();
+    }
+    return ARFE_OK;
+}
+
+extern "C" int32_t arfe_roialign_bwd_prepared(const arfe_pyramid_t* pyr, float* const* dfeats, const int32_t* strides,
+                                              int32_t nsets, int32_t R, const float* const* rois,
+                                              const int64_t* const* levels, int32_t pooled, int32_t sample_num,
+                                              const float* gout, int64_t gout_roi_stride, const void* workspace,
+                                              void* stream) {
     int32_t rc = check_pyramid(pyr);
     if (rc) return rc;
     ARFE_CHECK_ARG(R >= 0 && nsets >= 1 && nsets <= RB_MAXSETS && sample_num >= 0, ARFE_ERR_ARG, "roialign_bwd: bad arguments");
@@ -788,57 +895,30 @@ extern "C" int32_t arfe_roialign_bwd(const arfe_pyramid_t* pyr, float* const* df
     RoiLevels L;
     ARFE_CHECK_ARG(fill_roi_levels(L, pyr, nullptr, dfeats, strides) == ARFE_OK, ARFE_ERR_ARG, "roialign_bwd: bad level table");
     RoiSets S;
-    S.nsets = nsets; S.R = R;
-    for (int i = 0; i < RB_MAXSETS; ++i) { S.rois[i] = nullptr; S.levels[i] = nullptr; }
-    for (int i = 0; i < nsets && R > 0; ++i) {
-        ARFE_CHECK_ARG(rois[i] && levels[i], ARFE_ERR_ARG, "roialign_bwd: null RoI set %d", i);
-        S.rois[i] = rois[i]; S.levels[i] = levels[i];
-    }
-    int ntiles, mx;
-    RoiTileTable T = make_roi_tile_table(pyr, &ntiles, &mx);
-    int* counts = (int*)workspace;
-    int* offsets = counts + ntiles;
-    int* cursors = offsets + ntiles + 1;
-    int* list = cursors + ntiles;
-    const int nroi_all = nsets * R;
-    int* lmeta = list + (size_t)nroi_all * mx;
-    uintptr_t after = (uintptr_t)(lmeta + (size_t)nroi_all * mx);
-    after = (after + 15) & ~(uintptr_t)15;
-    RoiWeightHdr* hdr = (RoiWeightHdr*)after;
-    float* wtab = (float*)(hdr + nroi_all);
+    rc = fill_roi_sets(S, nsets, R, rois, levels, "roialign_bwd");
+    if (rc) return rc;
+    RoiBwdPlan p = plan_roi_bwd(pyr, nsets, R, const_cast<void*>(workspace));
     hipStream_t st = as_stream(stream);
-    {   // the tile counters (the gradient maps: see roi_zero_sliced_tiles_kernel)
-        ZeroList z;
-        z.add(counts, ntiles);
-        rc = zero_buffers(z, st);
-        if (rc) return rc;
-    }
-    const int nroi = nsets * R;
-    if (nroi > 0) {
-        hipLaunchKernelGGL((roi_bin_kernel<false>), dim3(cdiv(nroi, 256)), dim3(256), 0, st, L, S, T, pooled, counts,
-                           (const int*)offsets, cursors, list, (const RoiWeightHdr*)nullptr, (int*)nullptr);
-        ARFE_CHECK_LAUNCH();
-        hipLaunchKernelGGL(roi_weight_table_kernel, dim3(nroi), dim3(256), 0, st, L, S, pooled, sample_num, hdr, wtab,
-                           (const int32_t*)nullptr, 1);
-        ARFE_CHECK_LAUNCH();
-    }
-    hipLaunchKernelGGL(roi_bin_scan_kernel, dim3(1), dim3(1024), 0, st, (const int*)counts, offsets, cursors, ntiles);
-    ARFE_CHECK_LAUNCH();
-    if (nroi > 0) {
-        hipLaunchKernelGGL((roi_bin_kernel<true>), dim3(cdiv(nroi, 256)), dim3(256), 0, st, L, S, T, pooled, counts,
-                           (const int*)offsets, cursors, list, (const RoiWeightHdr*)hdr, lmeta);
-        ARFE_CHECK_LAUNCH();
-    }
     const int nchunks = cdiv(L.C, RB_CC);
-    ARFE_CHECK_ARG((int64_t)ntiles * nchunks < (int64_t)1 << 31, ARFE_ERR_ARG, "roialign_bwd: pyramid too large");
-    hipLaunchKernelGGL(roi_zero_sliced_tiles_kernel, dim3(ntiles * nchunks), dim3(256), 0, st, L, T, (const int*)offsets, ntiles,
-                       nchunks);
+    ARFE_CHECK_ARG((int64_t)p.ntiles * nchunks < (int64_t)1 << 31, ARFE_ERR_ARG, "roialign_bwd: pyramid too large");
+    hipLaunchKernelGGL(roi_zero_sliced_tiles_kernel, dim3(p.ntiles * nchunks), dim3(256), 0, st, L, p.T, (const int*)p.offsets,
+                       p.ntiles, nchunks);
     ARFE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(roialign_bwd_tiles_kernel, dim3(ntiles * nchunks, 1, RB_SEGS), dim3(256), 0, st, L, S, T, pooled,
-                       sample_num, gout, gout_roi_stride, (const int*)offsets, (const int*)list, (const int*)lmeta,
-                       (const float*)wtab, ntiles, nchunks);
+    hipLaunchKernelGGL(roialign_bwd_tiles_kernel, dim3(p.ntiles * nchunks, 1, RB_SEGS), dim3(256), 0, st, L, S, p.T, pooled,
+                       sample_num, gout, gout_roi_stride, (const int*)p.offsets, (const int*)p.list, (const int*)p.lmeta,
+                       (const float*)p.wtab, p.ntiles, nchunks);
     ARFE_CHECK_LAUNCH();
     return ARFE_OK;
+}
+
+extern "C" int32_t arfe_roialign_bwd(const arfe_pyramid_t* pyr, float* const* dfeats, const int32_t* strides,
+                                     int32_t nsets, int32_t R, const float* const* rois, const int64_t* const* levels,
+                                     int32_t pooled, int32_t sample_num, const float* gout, int64_t gout_roi_stride,
+                                     void* workspace, void* stream) {
+    int32_t rc = arfe_roialign_bwd_prepare(pyr, strides, nsets, R, rois, levels, pooled, sample_num, workspace, stream);
+    if (rc) return rc;
+    return arfe_roialign_bwd_prepared(pyr, dfeats, strides, nsets, R, rois, levels, pooled, sample_num, gout, gout_roi_stride,
+                                      workspace, stream);
 }
 
 extern "C" int32_t arfe_rff_fuse_fwd(int32_t R, int32_t C, const float* ori, int64_t ori_roi_stride, const float* lw,

@@ -288,6 +288,18 @@ def map_roi_levels_op(rois, num_levels, finest_scale=56):
     return lv
 
 
+def rff_roi_sets_op(rois, num_levels, finest_scale=56):
+    """-> (h_rois, w_rois, [levels_ori, levels_w, levels_h]): get_adaptive_scale_rois(rois, 1) and the level of every
+    RoI of the three sets, one launch."""
+    hip.require_f32_cuda(rois)
+    R, dev = rois.shape[0], rois.device
+    h_rois, w_rois = torch.empty_like(rois), torch.empty_like(rois)
+    lv = [torch.empty(R, dtype=torch.int64, device=dev) for _ in range(3)]
+    check(hip.lib().arfe_rff_roi_sets(R, ptr(rois), num_levels, float(finest_scale), ptr(h_rois), ptr(w_rois), ptr(lv[0]),
+                                      ptr(lv[1]), ptr(lv[2]), stream()), "arfe_rff_roi_sets")
+    return h_rois, w_rois, lv
+
+
 def _stride_array(strides):
     arr = (_i32 * hip.MAX_LEVELS)()
     for i, s in enumerate(strides):
@@ -307,51 +319,91 @@ def roialign_fwd_op(feats, strides, roi_sets, level_sets, out, pooled=7, sample_
                                           out.stride(0), ptr(ws), stream()), "arfe_roialign_fwd")
 
 
-def roialign_bwd_op(shapes, strides, roi_sets, level_sets, gout, pooled=7, sample_num=0):
-    """d(feats) of all RoI sets at once; every element is written by the kernel (no zero-fill, no atomics)."""
+def roialign_bwd_prepare_op(feats, strides, roi_sets, level_sets, pooled=7, sample_num=0):
+    """The RoI-only part of the backward (tile lists, weight tables) -> workspace tensor; launched on the CURRENT stream
+    (RoIExtractFunction.forward puts it on the side stream, beside the forward RoIAlign)."""
+    pyr = Pyramid.of(feats, 0)
+    nsets, R = len(roi_sets), roi_sets[0].shape[0]
+    ws = _ws(hip.lib().arfe_roialign_bwd_workspace_bytes(ctypes.byref(pyr), nsets, R), feats[0].device)
+    check(hip.lib().arfe_roialign_bwd_prepare(ctypes.byref(pyr), _stride_array(strides), nsets, R, ptr_array(roi_sets),
+                                              ptr_array(level_sets), pooled, sample_num, ptr(ws), stream()),
+          "arfe_roialign_bwd_prepare")
+    return ws
+
+
+def roialign_bwd_op(shapes, strides, roi_sets, level_sets, gout, pooled=7, sample_num=0, prepared=None):
+    """d(feats) of all RoI sets at once; every element is written by the kernel (no zero-fill, no atomics).
+    prepared: the workspace of roialign_bwd_prepare_op (already ordered before the current stream), or None."""
     dev = gout.device
     dfeats = [torch.empty(shape, device=dev) for shape in shapes]
     pyr = Pyramid.of(dfeats, 0)
     nsets, R = len(roi_sets), roi_sets[0].shape[0]
-    ws = _ws(hip.lib().arfe_roialign_bwd_workspace_bytes(ctypes.byref(pyr), nsets, R), dev)
     with probe('roialign_bwd'):
-        check(hip.lib().arfe_roialign_bwd(ctypes.byref(pyr), ptr_array(dfeats), _stride_array(strides), nsets, R,
-                                          ptr_array(roi_sets), ptr_array(level_sets), pooled, sample_num, ptr(gout),
-                                          gout.stride(0), ptr(ws), stream()), "arfe_roialign_bwd")
+        if prepared is None:
+            ws = _ws(hip.lib().arfe_roialign_bwd_workspace_bytes(ctypes.byref(pyr), nsets, R), dev)
+            check(hip.lib().arfe_roialign_bwd(ctypes.byref(pyr), ptr_array(dfeats), _stride_array(strides), nsets, R,
+                                              ptr_array(roi_sets), ptr_array(level_sets), pooled, sample_num, ptr(gout),
+                                              gout.stride(0), ptr(ws), stream()), "arfe_roialign_bwd")
+        else:
+            check(hip.lib().arfe_roialign_bwd_prepared(ctypes.byref(pyr), ptr_array(dfeats), _stride_array(strides), nsets,
+                                                       R, ptr_array(roi_sets), ptr_array(level_sets), pooled, sample_num,
+                                                       ptr(gout), gout.stride(0), ptr(prepared), stream()),
+                  "arfe_roialign_bwd_prepared")
     return dfeats
 
 
 class RoIExtractFunction(torch.autograd.Function):
     """SingleRoIExtractor.forward for `nsets` RoI sets at once; set s fills channels [s*C, (s+1)*C) of the
     [R, nsets*C, P, P] output (the concat of standard_roi_head.py:155 without a copy).
-    args: strides, finest_scale, pooled, sample_num, nsets, rois_0..rois_{nsets-1}, feat_0..feat_{n-1}"""
+    args: strides, finest_scale, pooled, sample_num, nsets, have_levels, rois_0..rois_{nsets-1},
+          [levels_0..levels_{nsets-1} when have_levels], feat_0..feat_{n-1}"""
 
     @staticmethod
-    def forward(ctx, strides, finest_scale, pooled, sample_num, nsets, *t):
+    def forward(ctx, strides, finest_scale, pooled, sample_num, nsets, have_levels, *t):
         roi_sets = [r.contiguous() for r in t[:nsets]]
-        feats = [f.contiguous() for f in t[nsets:]]
+        nl = nsets if have_levels else 0
+        feats = [f.contiguous() for f in t[nsets + nl:]]
         R, C = roi_sets[0].shape[0], feats[0].shape[1]
-        out = torch.empty(R, nsets * C, pooled, pooled, device=feats[0].device)
-        levels = [map_roi_levels_op(rois, len(feats), finest_scale) for rois in roi_sets]
+        dev = feats[0].device
+        out = torch.empty(R, nsets * C, pooled, pooled, device=dev)
+        if have_levels:
+            levels = [l.contiguous() for l in t[nsets:nsets + nl]]
+        else:
+            levels = [map_roi_levels_op(rois, len(feats), finest_scale) for rois in roi_sets]
+        need_grad = any(ctx.needs_input_grad[6 + nsets + nl:])
+        prepared, ctx.prep_event = None, None
         if R > 0:
+            if need_grad:
+                # the backward's RoI-only half (tile lists, weight tables: six small dependent launches) runs on the
+                # side stream beside the forward kernel instead of in front of the backward kernel
+                prepared = on_side(dev, lambda: roialign_bwd_prepare_op(feats, strides, roi_sets, levels, pooled, sample_num))
+                ctx.prep_event = side_stream(dev).record_event()
             roialign_fwd_op(feats, strides, roi_sets, levels, out, pooled, sample_num)
         ctx.cfg = (tuple(strides), pooled, sample_num, nsets, C)
         ctx.shapes = [f.shape for f in feats]
-        ctx.save_for_backward(*roi_sets, *levels)
+        ctx.has_prepared = prepared is not None
+        ctx.save_for_backward(*roi_sets, *levels, *([prepared] if prepared is not None else []))
         return out
 
     @staticmethod
     def backward(ctx, gout):
         strides, pooled, sample_num, nsets, C = ctx.cfg
         s = ctx.saved_tensors
-        roi_sets, levels = s[:nsets], s[nsets:]
+        roi_sets, levels = s[:nsets], s[nsets:2 * nsets]
+        prepared = s[2 * nsets] if ctx.has_prepared else None
         gout = gout.contiguous()
-        dfeats = roialign_bwd_op(ctx.shapes, strides, list(roi_sets), list(levels), gout, pooled, sample_num)
-        return (None, None, None, None, None, *([None] * nsets), *dfeats)
+        if prepared is not None:
+            torch.cuda.current_stream().wait_event(ctx.prep_event)
+        dfeats = roialign_bwd_op(ctx.shapes, strides, list(roi_sets), list(levels), gout, pooled, sample_num, prepared)
+        nl = len(ctx.needs_input_grad) - 6 - nsets - len(dfeats)
+        return (None, None, None, None, None, None, *([None] * (nsets + nl)), *dfeats)
 
 
-def roi_extract(feats, roi_sets, strides, finest_scale=56, pooled=7, sample_num=0):
-    return RoIExtractFunction.apply(tuple(strides), finest_scale, pooled, sample_num, len(roi_sets), *roi_sets, *feats)
+def roi_extract(feats, roi_sets, strides, finest_scale=56, pooled=7, sample_num=0, levels=None):
+    """levels: optional precomputed int64 level of every RoI of every set (rff_roi_sets_op); else map_roi_levels per set."""
+    lv = list(levels) if levels is not None else []
+    return RoIExtractFunction.apply(tuple(strides), finest_scale, pooled, sample_num, len(roi_sets), levels is not None,
+                                    *roi_sets, *lv, *feats)
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -416,12 +468,23 @@ def linear_bwd_weight_op(x, w, dy):
     return dw, db
 
 
+def rff_prepack(w_wh, w_hh, w_f):
+    """The three conv weights in the kernels' layouts, launched on the side stream: a caller that knows the head is
+    coming (StandardRoIHead._bbox_forward) issues this before the RoI extraction, so the re-layout runs beside the
+    RoIAlign kernel instead of in front of the first conv.  The head joins the side stream before it reads them."""
+    ws = [w.detach().contiguous() for w in (w_wh, w_hh, w_f)]
+    hip.require_f32_cuda(*ws)
+    return on_side(ws[0].device, lambda: tuple(conv3x3_pack_op(w) for w in ws))
+
+
 class RFFHeadFunction(torch.autograd.Function):
     """MultiBBoxHead.forward (num_shared_fcs=2): x [R,3C,7,7] -> (cls_score, bbox_pred).
-    args: x, w_wh, b_wh, w_hh, b_hh, w_f, b_f, w_fc1, b_fc1, w_fc2, b_fc2, w_cls, b_cls, w_reg, b_reg"""
+    args: x, w_wh, b_wh, w_hh, b_hh, w_f, b_f, w_fc1, b_fc1, w_fc2, b_fc2, w_cls, b_cls, w_reg, b_reg,
+          [pk_wh, pk_hh, pk_f from rff_prepack of the same weights, or None]"""
 
     @staticmethod
-    def forward(ctx, x, w_wh, b_wh, w_hh, b_hh, w_f, b_f, w1, b1, w2, b2, wc, bc, wr, br):
+    def forward(ctx, x, w_wh, b_wh, w_hh, b_hh, w_f, b_f, w1, b1, w2, b2, wc, bc, wr, br, pk_wh=None, pk_hh=None,
+                pk_f=None):
         x = x.contiguous()
         params = [p.contiguous() for p in (w_wh, b_wh, w_hh, b_hh, w_f, b_f, w1, b1, w2, b2, wc, bc, wr, br)]
         w_wh, b_wh, w_hh, b_hh, w_f, b_f, w1, b1, w2, b2, wc, bc, wr, br = params
@@ -429,7 +492,10 @@ class RFFHeadFunction(torch.autograd.Function):
         R, C3 = x.shape[0], x.shape[1]
         C = C3 // 3
         assert C3 == 3 * C and x.shape[2:] == (7, 7), "AR-RFF head expects [R, 3C, 7, 7]"
-        pk_wh, pk_hh, pk_f = conv3x3_pack_op(w_wh), conv3x3_pack_op(w_hh), conv3x3_pack_op(w_f)
+        if pk_wh is None:
+            pk_wh, pk_hh, pk_f = conv3x3_pack_op(w_wh), conv3x3_pack_op(w_hh), conv3x3_pack_op(w_f)
+        else:
+            join_side(x.device)          # the packs were launched on the side stream
         rs = C3 * 49
         base = x.data_ptr()
         # the two gating convs are independent: two 196-workgroup launches side by side pack the 256 CUs
@@ -441,8 +507,10 @@ class RFFHeadFunction(torch.autograd.Function):
         z2 = conv3x3_fwd_op(z.data_ptr(), C * 49, R, C, pk_f, b_f, True)
         f1 = linear_fwd_op(z2.view(R, C * 49), w1, b1, True)
         f2 = linear_fwd_op(f1, w2, b2, True)
+        # the two predictors are small, latency-bound and independent: side by side
+        reg = on_side(x.device, lambda: linear_fwd_op(f2, wr, br, False))
         cls = linear_fwd_op(f2, wc, bc, False)
-        reg = linear_fwd_op(f2, wr, br, False)
+        join_side(x.device)
         ctx.save_for_backward(x, w_wh, w_hh, w_f, w1, w2, wc, wr, lw, lh, z, z2, f1, f2, pk_wh, pk_hh, pk_f)
         return cls, reg
 
@@ -480,16 +548,19 @@ class RFFHeadFunction(torch.autograd.Function):
         dlh = torch.empty(R, C, 7, 7, device=dev)
         check(hip.lib().arfe_rff_fuse_bwd(R, C, x.data_ptr(), rs, ptr(lw), ptr(lh), ptr(dz), dx.data_ptr(), rs, ptr(dlw),
                                           ptr(dlh), stream()), "arfe_rff_fuse_bwd")
+        # side stream: the two weight gradients back to back; main stream: the two data gradients back to back (each pair
+        # of concurrent kernels fills the CUs the other leaves idle; three kernels in a row on one stream did not)
         dwwh, dbwh = side_do(lambda: conv3x3_bwd_weight_op(x.data_ptr() + 4 * C * 49, rs, R, C, w_wh, dlw, ws))
         dwhh, dbhh = side_do(lambda: conv3x3_bwd_weight_op(x.data_ptr() + 8 * C * 49, rs, R, C, w_hh, dlh, ws))
-        side_do(lambda: conv3x3_bwd_data_op(R, C, pk_hh, dlh, dx.data_ptr() + 8 * C * 49, rs))
         conv3x3_bwd_data_op(R, C, pk_wh, dlw, dx.data_ptr() + 4 * C * 49, rs)
+        conv3x3_bwd_data_op(R, C, pk_hh, dlh, dx.data_ptr() + 8 * C * 49, rs)
         join_side(dev)
-        return dx, dwwh, dbwh, dwhh, dbhh, dwf, dbf, dw1, db1, dw2, db2, dwc, dbc, dwr, dbr
+        return (dx, dwwh, dbwh, dwhh, dbhh, dwf, dbf, dw1, db1, dw2, db2, dwc, dbc, dwr, dbr, None, None, None)
 
 
-def rff_head(x, w_wh, b_wh, w_hh, b_hh, w_f, b_f, w1, b1, w2, b2, wc, bc, wr, br):
-    return RFFHeadFunction.apply(x, w_wh, b_wh, w_hh, b_hh, w_f, b_f, w1, b1, w2, b2, wc, bc, wr, br)
+def rff_head(x, w_wh, b_wh, w_hh, b_hh, w_f, b_f, w1, b1, w2, b2, wc, bc, wr, br, packed=None):
+    pk = tuple(packed) if packed is not None else (None, None, None)
+    return RFFHeadFunction.apply(x, w_wh, b_wh, w_hh, b_hh, w_f, b_f, w1, b1, w2, b2, wc, bc, wr, br, *pk)
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -51,10 +51,13 @@ SIGNATURES = {
     "arfe_nonlocal_bwd": (_i32, [_i32, _i32, _i32] + [_vp] * 21),
     "arfe_rff_make_rois": (_i32, [_i32, _vp, _vp, _vp, _vp]),
     "arfe_map_roi_levels": (_i32, [_i32, _vp, _i32, _f32, _vp, _vp]),
+    "arfe_rff_roi_sets": (_i32, [_i32, _vp, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "arfe_roialign_fwd_workspace_bytes": (_i64, [_i32, _i32]),
     "arfe_roialign_fwd": (_i32, [_PP, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp]),
     "arfe_roialign_bwd_workspace_bytes": (_i64, [_PP, _i32, _i32]),
     "arfe_roialign_bwd": (_i32, [_PP, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp]),
+    "arfe_roialign_bwd_prepare": (_i32, [_PP, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp]),
+    "arfe_roialign_bwd_prepared": (_i32, [_PP, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp]),
     "arfe_conv3x3_packed_bytes": (_i64, [_i32]),
     "arfe_conv3x3_workspace_bytes": (_i64, [_i32]),
     "arfe_conv3x3_pack_weights": (_i32, [_i32, _vp, _vp, _vp]),

@@ -27,7 +27,7 @@ class RoIAlign(nn.Module):
     def forward(self, features, rois):
         assert rois.dim() == 2 and rois.size(1) == 5
         # one level: every RoI maps to level 0
-        return Fn.RoIExtractFunction.apply((self._stride,), 1e30, self.out_size[0], self.sample_num, 1, rois, features)
+        return Fn.RoIExtractFunction.apply((self._stride,), 1e30, self.out_size[0], self.sample_num, 1, False, rois, features)
 
     def __repr__(self):
         return (f"{self.__class__.__name__}(out_size={self.out_size}, spatial_scale={self.spatial_scale}, "

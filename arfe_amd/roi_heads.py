@@ -59,11 +59,20 @@ class SingleRoIExtractor(nn.Module):
         fp32 inside and half out in fp16 mode, like `forward` (single_level.py:109)."""
         return self._extract(feats, roi_sets)
 
-    def _extract(self, feats, roi_sets):
+    @force_fp32(apply_to=('feats', ), out_fp16=True)
+    def extract_ar_sets(self, feats, rois):
+        """The AR-RFF body of `_bbox_forward` (standard_roi_head.py:138-155): get_adaptive_scale_rois(rois, 1), the level
+        of every RoI of the three sets (one launch for both) and the [ori, lw, lh] channel concat."""
+        feats = list(feats)[:self.num_inputs]
+        rois = rois.float().contiguous()
+        lh_rois, lw_rois, (lv_ori, lv_w, lv_h) = Fn.rff_roi_sets_op(rois, len(feats), self.finest_scale)
+        return self._extract(feats, [rois, lw_rois, lh_rois], [lv_ori, lv_w, lv_h])
+
+    def _extract(self, feats, roi_sets, levels=None):
         layer = self.roi_layers[0]
         feats = list(feats)[:self.num_inputs]
         return Fn.roi_extract(feats, [r.float() for r in roi_sets], self.featmap_strides[:len(feats)], self.finest_scale,
-                              layer.out_size[0], layer.sample_num)
+                              layer.out_size[0], layer.sample_num, levels)
 
 
 @HEADS.register_module()
@@ -144,7 +153,15 @@ class MultiBBoxHead(BBoxHead):
             if isinstance(m, nn.Conv2d):
                 xavier_init(m, distribution='uniform')
 
-    def forward(self, x):
+    def prepack(self):
+        """Launch the re-layout of the three conv weights on the side stream (fp32 mode; returns None in fp16 mode, where
+        the parameters first pass the half -> float boundary inside forward).  Pass the result to forward(x, packed)."""
+        ws = (self.wh_conv.conv.weight, self.hh_conv.conv.weight, self.final_conv.conv.weight)
+        if any(w.dtype != torch.float32 or not w.is_cuda for w in ws):
+            return None
+        return Fn.rff_prepack(*ws)
+
+    def forward(self, x, packed=None):
         # no @auto_fp16 on this forward in the reference (multirois_bbox_head.py:165): in fp16 mode x arrives as half
         # from the extractor (out_fp16) and meets half parameters
         params = [self.wh_conv.conv.weight, self.wh_conv.conv.bias, self.hh_conv.conv.weight, self.hh_conv.conv.bias,
@@ -152,7 +169,7 @@ class MultiBBoxHead(BBoxHead):
                   self.shared_fcs[0].bias, self.shared_fcs[1].weight, self.shared_fcs[1].bias, self.fc_cls.weight,
                   self.fc_cls.bias, self.fc_reg.weight, self.fc_reg.bias]
         (x,), p, finish = Fn.f32_boundary([x], params, 'MultiBBoxHead')
-        return finish(Fn.rff_head(x, *p))
+        return finish(Fn.rff_head(x, *p, packed=packed if x.dtype == torch.float32 else None))
 
 
 @HEADS.register_module()
@@ -187,11 +204,10 @@ class StandardRoIHead(nn.Module):
 
     def _bbox_forward(self, x, rois):
         n = self.bbox_roi_extractor.num_inputs
-        rois = rois.float().contiguous()
-        lh_rois, lw_rois = get_adaptive_scale_rois(rois, 1)
-        # torch.cat([ori, lw, lh], dim=1) of the reference, produced in place by the fused extractor
-        bbox_feats = self.bbox_roi_extractor.extract_sets(x[:n], [rois, lw_rois, lh_rois])
-        cls_score, bbox_pred = self.bbox_head(bbox_feats)
+        packed = self.bbox_head.prepack()      # weight re-layout on the side stream, beside the RoIAlign kernel
+        # get_adaptive_scale_rois + torch.cat([ori, lw, lh], dim=1) of the reference, produced in place by the fused extractor
+        bbox_feats = self.bbox_roi_extractor.extract_ar_sets(x[:n], rois)
+        cls_score, bbox_pred = self.bbox_head(bbox_feats, packed)
         return dict(cls_score=cls_score, bbox_pred=bbox_pred, bbox_feats=bbox_feats)
 
     def forward_dummy(self, x, proposals):
@@ -244,10 +260,9 @@ class CascadeRoIHead(nn.Module):
     def _bbox_forward(self, stage, x, rois):
         bbox_roi_extractor = self.bbox_roi_extractor[stage]
         bbox_head = self.bbox_head[stage]
-        rois = rois.float().contiguous()
-        lh_rois, lw_rois = get_adaptive_scale_rois(rois, 1)
-        bbox_feats = bbox_roi_extractor.extract_sets(x[:bbox_roi_extractor.num_inputs], [rois, lw_rois, lh_rois])
-        cls_score, bbox_pred = bbox_head(bbox_feats)
+        packed = bbox_head.prepack()
+        bbox_feats = bbox_roi_extractor.extract_ar_sets(x[:bbox_roi_extractor.num_inputs], rois)
+        cls_score, bbox_pred = bbox_head(bbox_feats, packed)
         return dict(cls_score=cls_score, bbox_pred=bbox_pred, bbox_feats=bbox_feats)
 
     def forward_dummy(self, x, proposals):

@@ -126,6 +126,12 @@ int32_t arfe_rff_make_rois(int32_t R, const float* rois, float* h_rois, float* w
 int32_t arfe_map_roi_levels(int32_t R, const float* rois, int32_t num_levels, float finest_scale,
                             int64_t* levels, void* stream);
 
+/* The AR-RFF glue of _bbox_forward (standard_roi_head.py:138-150) in one launch: arfe_rff_make_rois followed by
+ * arfe_map_roi_levels of the original, the w- and the h-RoI set (each enlarged RoI gets its own level).  Results are
+ * bit-identical to the separate calls. */
+int32_t arfe_rff_roi_sets(int32_t R, const float* rois, int32_t num_levels, float finest_scale, float* h_rois,
+                          float* w_rois, int64_t* levels_ori, int64_t* levels_w, int64_t* levels_h, void* stream);
+
 /* RoIAlign v2 (aligned=True, sample_num=0 -> adaptive grid; mmdet/ops/roi_align/src/cpu/roi_align_v2.cpp
  * :107-191 fwd, :247-332 bwd; CUDA kernels src/cuda/roi_align_kernel_v2.cu:63-129,180-) fused with the
  * per-level dispatch of SingleRoIExtractor.forward (single_level.py:109-152) for `nsets` RoI sets at once:
@@ -149,6 +155,17 @@ int32_t arfe_roialign_bwd(const arfe_pyramid_t* pyr, float* const* dfeats, const
                           int32_t R, const float* const* rois, const int64_t* const* levels, int32_t pooled,
                           int32_t sample_num, const float* gout, int64_t gout_roi_stride, void* workspace,
                           void* stream);
+/* The same backward in two calls: _prepare does everything that depends on the RoIs alone (tile lists, per-RoI
+ * weight tables) into `workspace`, so a caller can run it beside the forward RoIAlign on another stream; _prepared
+ * consumes that workspace (same pyr / strides / RoI sets) once the upstream gradient exists.
+ * arfe_roialign_bwd == _prepare followed by _prepared on one stream. */
+int32_t arfe_roialign_bwd_prepare(const arfe_pyramid_t* pyr, const int32_t* strides, int32_t nsets, int32_t R,
+                                  const float* const* rois, const int64_t* const* levels, int32_t pooled,
+                                  int32_t sample_num, void* workspace, void* stream);
+int32_t arfe_roialign_bwd_prepared(const arfe_pyramid_t* pyr, float* const* dfeats, const int32_t* strides, int32_t nsets,
+                                   int32_t R, const float* const* rois, const int64_t* const* levels, int32_t pooled,
+                                   int32_t sample_num, const float* gout, int64_t gout_roi_stride,
+                                   const void* workspace, void* stream);
 
 /* 3x3 conv, padding 1, on RoI features [R, C, 7, 7] (MultiBBoxHead wh_conv/hh_conv/final_conv,
  * bbox_heads/multirois_bbox_head.py:50-78,172-173,183) as an implicit GEMM on the matrix cores.

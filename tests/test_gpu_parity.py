@@ -209,6 +209,52 @@ def test_map_roi_levels_bit_exact(Fn, O, dev):
     assert Fn.map_roi_levels_op(torch.zeros(0, 5, device=dev), 5).numel() == 0
 
 
+def test_rff_roi_sets_single_launch_is_bit_exact(Fn, O, dev):
+    """arfe_rff_roi_sets == arfe_rff_make_rois + 3 x arfe_map_roi_levels, against the golden RoIs and the oracle."""
+    d = load_golden('rois_make.npz')
+    h, w, lv = Fn.rff_roi_sets_op(d['rois'].to(dev), 5)
+    assert torch.equal(h.cpu(), d['h_rois']) and torch.equal(w.cpu(), d['w_rois'])
+    rois = torch.cat([O.synth_rois(2, 512), load_golden('roi_levels.npz')['rois']])
+    ho, wo = O.make_rois(rois)
+    for nl in (5, 4):
+        h, w, lv = Fn.rff_roi_sets_op(rois.to(dev), nl)
+        assert torch.equal(h.cpu(), ho) and torch.equal(w.cpu(), wo)
+        for got, r in zip(lv, (rois, wo, ho)):          # level order: ori, w, h
+            assert got.dtype == torch.int64 and torch.equal(got.cpu(), O.map_roi_levels(r, nl))
+    h, w, lv = Fn.rff_roi_sets_op(torch.zeros(0, 5, device=dev), 5)
+    assert h.shape == (0, 5) and all(l.numel() == 0 for l in lv)
+
+
+def test_roialign_bwd_prepared_route_equals_single_call(Fn, O, dev):
+    """The backward split into _prepare (side stream, during the forward) + _prepared gives the gradients of
+    arfe_roialign_bwd (to summation order), and the autograd node that uses it matches the node fed with separately computed levels."""
+    g = torch.Generator().manual_seed(18)
+    C = 24
+    feats = [torch.randn(2, C, h, w, generator=g).to(dev) for h, w in PYRAMIDS['mid']]
+    rois = O.synth_rois(2, 90, img_w=384, img_h=256, seed=4).to(dev)
+    h_r, w_r, lv = Fn.rff_roi_sets_op(rois, 5)
+    sets = [rois, w_r, h_r]
+    gout = torch.randn(rois.shape[0], 3 * C, 7, 7, generator=g).to(dev)
+    shapes = [f.shape for f in feats]
+    one = Fn.roialign_bwd_op(shapes, O.STRIDES, sets, lv, gout)
+    ws = Fn.roialign_bwd_prepare_op(feats, O.STRIDES, sets, lv)
+    two = Fn.roialign_bwd_op(shapes, O.STRIDES, sets, lv, gout, prepared=ws)
+    for a, b in zip(one, two):
+        assert relerr(a, b) <= 1e-6         # the tile lists are filled through atomic cursors: summation order varies
+    fa = [f.clone().requires_grad_(True) for f in feats]
+    fb = [f.clone().requires_grad_(True) for f in feats]
+    ya = Fn.roi_extract(fa, sets, O.STRIDES)
+    yb = Fn.roi_extract(fb, sets, O.STRIDES, levels=lv)
+    assert torch.equal(ya, yb)
+    (ya * gout).sum().backward()
+    (yb * gout).sum().backward()
+    for a, b, c in zip(fa, fb, one):
+        assert relerr(a.grad, b.grad) <= 1e-6 and relerr(a.grad, c) <= 1e-6
+    # no gradient wanted: no prepare, forward still right
+    with torch.no_grad():
+        assert torch.equal(Fn.roi_extract(feats, sets, O.STRIDES, levels=lv), ya)
+
+
 def test_roialign_golden(Fn, dev):
     d = load_golden('roialign.npz')
     feats = [d[f'feat{i}'].to(dev).requires_grad_(True) for i in range(5)]
@@ -247,6 +293,25 @@ def test_roialign_realistic_geometry_matches_oracle(Fn, O, dev):
     (got * cot.to(dev)).sum().backward()
     for i in range(5):
         assert relerr(fd[i].grad, fo[i].grad if fo[i].grad is not None else torch.zeros_like(fo[i])) <= TOL_GRAD, i
+
+
+def test_rff_head_with_prepacked_weights_equals_plain_call(Fn, dev):
+    """MultiBBoxHead.prepack() (weight re-layout launched early on the side stream) changes scheduling only."""
+    import arfe_amd
+    torch.manual_seed(5)
+    head = arfe_amd.build_head(dict(type='MultiRoIsBBoxHead', in_channels=32, conv_out_channels=32, fc_out_channels=48,
+                                    roi_feat_size=7, num_classes=80)).to(dev)
+    head.init_weights()
+    x = torch.randn(70, 96, 7, 7, device=dev)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ca, ra = head(xa)
+    cb, rb = head(xb, head.prepack())
+    # split-K atomics: two plain calls differ by up to ~5e-6 (tools/probe/head_repeat.py); the bound is that noise
+    assert relerr(ca, cb) <= 3e-5 and relerr(ra, rb) <= 3e-5
+    ga = torch.autograd.grad((ca.sum() + ra.sum()), [xa] + list(head.parameters()))
+    gb = torch.autograd.grad((cb.sum() + rb.sum()), [xb] + list(head.parameters()))
+    for a, b in zip(ga, gb):
+        assert relerr(a, b) <= 1e-4
 
 
 @pytest.mark.parametrize('name', ['rff_head_r8.npz', 'rff_head_r40.npz'])
