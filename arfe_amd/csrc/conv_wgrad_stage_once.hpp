@@ -8,6 +8,9 @@
 //     (dx = -1, 0, +1; zeros shifted in): [3][64 ci][6 octets].  A tap's row shift dy is then a whole k-octet
 //     (octet lq + dy + 1 of copy dx + 1) and a lane whose shifted row leaves the RoI reads a zero octet.
 // Partial sums of the row slices are added atomically into the zeroed dWp (as the generic path does).
+// The bias gradient db[co] = sum_{r, p} dy[r][co][p] rides along: the threads that stage the dy rows of the ci-block-0
+// workgroups add up what they fetch (fp32, before the split) and add their totals to the zeroed db once at the end, so
+// the separate 51 MB reduction pass over dy is not needed.
 #pragma once
 #include "gemm_bf16x3.hpp"
 
@@ -27,7 +30,8 @@ struct WgradStageDims { int R, C, rows_total, rows_per_slice, tiles_ci; };
 
 __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_stage_once_kernel(WgradStageDims d, const float* __restrict__ x,
                                                                           int64_t x_roi_stride, const float* __restrict__ dy,
-                                                                          int64_t dy_roi_stride, float* __restrict__ dwp) {
+                                                                          int64_t dy_roi_stride, float* __restrict__ dwp,
+                                                                          float* __restrict__ db) {
     extern __shared__ __attribute__((aligned(16))) unsigned short ws_lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, l15 = lane & 15, lq = lane >> 4;
@@ -64,6 +68,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_stage_once_kernel(WgradS
     const int b_ci = tid & 63, b_o = __builtin_amdgcn_readfirstlane(b_on ? tid >> 6 : 0);   // x: octet o = row (first row - 1 + o)
     const int b_off = b_ci * WS_B_LD + 8 * b_o;
     float ra[8], rb[8];
+    float bias_sum = 0.f;                                    // this thread's share of db[co0 + a_co] (ci block 0 only)
     auto fetch = [&](int step) {
         const int g0 = row_begin + 4 * step;
         {
@@ -87,6 +92,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_stage_once_kernel(WgradS
                 for (int j = 0; j < 7; ++j) ra[j] = t[j + 1];
             }
             ra[7] = 0.f;
+            bias_sum += ((ra[0] + ra[1]) + (ra[2] + ra[3])) + ((ra[4] + ra[5]) + ra[6]);
         }
         if (b_on) {
             const int g = g0 - 1 + b_o;
@@ -203,6 +209,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_stage_once_kernel(WgradS
         buf ^= 1;
     }
 
+    if (db && ci0 == 0) unsafeAtomicAdd(db + co0 + a_co, bias_sum);
     // ---- epilogue: D layout lane -> column l15 (ci), rows 4*lq + r (co) ----
 #pragma unroll
     for (int t = 0; t < 9; ++t)
@@ -219,9 +226,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_stage_once_kernel(WgradS
             }
 }
 
-// -> true when the kernel ran (C a multiple of 128, bf16x3 mode, ARFE_CONV_STAGE_ONCE != 0); dwp must be zeroed before
+// -> true when the kernel ran (C a multiple of 128, bf16x3 mode, ARFE_CONV_STAGE_ONCE != 0); dwp and db must be zeroed
+// before; db (may be null) receives the bias gradient
 static inline bool launch_conv_wgrad_stage_once(int R, int C, const float* x, int64_t x_roi_stride, const float* dy,
-                                                int64_t dy_roi_stride, float* dwp, hipStream_t stream, int32_t* rc) {
+                                                int64_t dy_roi_stride, float* dwp, float* db, hipStream_t stream, int32_t* rc) {
     static const char* sw = getenv("ARFE_CONV_STAGE_ONCE");
     *rc = ARFE_OK;
     if ((sw && sw[0] == '0') || gemm_use_f32() || C % WS_CO != 0 || R < 64) return false;
@@ -240,7 +248,7 @@ static inline bool launch_conv_wgrad_stage_once(int R, int C, const float* x, in
     d.rows_per_slice = ((cdiv(d.rows_total, nslices) + 3) / 4) * 4;
     nslices = cdiv(d.rows_total, d.rows_per_slice);
     hipLaunchKernelGGL(conv3x3_wgrad_stage_once_kernel, dim3(nslices, tiles), dim3(512), WS_LDS_BYTES, stream, d, x, x_roi_stride,
-                       dy, dy_roi_stride, dwp);
+                       dy, dy_roi_stride, dwp, db);
     if (hipGetLastError() != hipSuccess) { set_error("conv3x3 wgrad stage-once launch failed"); *rc = ARFE_ERR_LAUNCH; }
     return true;
 }

@@ -592,8 +592,10 @@ extern "C" int32_t arfe_conv3x3_bwd_weight(int32_t R, int32_t C, const float* x,
     EpiPlain e = epi_plain(dwp, (int64_t)C * C, C);
     e.atomic = 1;
     int32_t rc;
-    if (launch_conv_wgrad_stage_once(R, C, x, x_roi_stride, dy, dy_roi_stride, dwp, st, &rc)) {
-        // (the nine taps in one kernel, operands staged once per pixel chunk: conv_wgrad_stage_once.hpp)
+    bool db_done = false;
+    if (launch_conv_wgrad_stage_once(R, C, x, x_roi_stride, dy, dy_roi_stride, dwp, db, st, &rc)) {
+        // (the nine taps in one kernel, operands staged once per pixel chunk: conv_wgrad_stage_once.hpp; it also sums db)
+        db_done = true;
     } else if (zvar) {
         GemmDims zv;
         const int tiles = cdiv(C, XL_BM) * cdiv(C, XL_BN);
@@ -639,10 +641,12 @@ extern "C" int32_t arfe_conv3x3_bwd_weight(int32_t R, int32_t C, const float* x,
     if (rc) return rc;
     hipLaunchKernelGGL(conv_dw_unpermute_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, dwp, dw, C);
     ARFE_CHECK_LAUNCH();
-    int chunk = 64;
-    dim3 grid(C, cdiv(R, chunk));
-    hipLaunchKernelGGL(reduce_mid_kernel, grid, dim3(256), 0, st, dy, (const float*)nullptr, db, R, dy_roi_stride, 49, chunk);
-    ARFE_CHECK_LAUNCH();
+    if (!db_done) {
+        int chunk = 64;
+        dim3 grid(C, cdiv(R, chunk));
+        hipLaunchKernelGGL(reduce_mid_kernel, grid, dim3(256), 0, st, dy, (const float*)nullptr, db, R, dy_roi_stride, 49, chunk);
+        ARFE_CHECK_LAUNCH();
+    }
     return ARFE_OK;
 }
 
