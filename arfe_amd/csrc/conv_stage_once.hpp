@@ -6,6 +6,12 @@
 // tile boundary may cut an RoI) and the nine taps read ROW-SHIFTED B fragments from it; a lane whose source pixel is
 // outside the 7x7 map reads a zero row instead (address select, no arithmetic on the data).  Only the pre-split weights are
 // staged per (tap, slice).  Same tile, wave layout, MFMA (v_mfma_f32_16x16x32_bf16) and epilogue as the 256x224 kernel.
+// Round 2: the weights are stored by the pack kernel as two bf16 PLANES (hi, lo) [tap][m][k] and go global -> LDS by
+// LDS-DMA (global_load_lds_dwordx4, 16 B per lane, 4 per wave and K-step): no staging registers, no unpack, no
+// ds_write for the A operand (32 KB per K-step, nine times the bytes of the activation image).  The LDS image is
+// lane-linear per wave-instruction (16 rows x 4 octets), so the XOR swizzle of the rows (xs_swz) is applied to the SOURCE
+// octet each lane fetches.  The step's DMA is issued at the top of the iteration into the other buffer and has the whole
+// MFMA phase to land; the barrier that ends the iteration (vmcnt(0) + s_barrier) retires it.
 #pragma once
 #include "gemm_bf16x3.hpp"
 
@@ -17,10 +23,10 @@ constexpr int CS_A_IMG = XL_BM * XS_LD;                                     // A
 constexpr int CS_B_IMG = (CS_ROWS + 1) * CS_BLD;
 constexpr int CS_LDS_BYTES = (2 * 2 * CS_A_IMG + 2 * 2 * CS_B_IMG) * 2;     // 2 buffers x (hi, lo) of each operand
 
-struct ConvStageDims { int M, N, C, tiles_n; };
+struct ConvStageDims { int M, N, C, tiles_n, dbg; };   // dbg: probe switches (ARFE_CONV_DBG), 0 in production
 
 template <class EPI>
-__global__ __launch_bounds__(512, 2) void conv3x3_stage_once_kernel(ConvStageDims d, const float* __restrict__ wsplit,
+__global__ __launch_bounds__(512, 2) void conv3x3_stage_once_kernel(ConvStageDims d, const unsigned short* __restrict__ wplanes,
                                                                     const float* __restrict__ x, int64_t roi_stride, EPI epi) {
     extern __shared__ __attribute__((aligned(16))) unsigned short cs_lds[];
     auto img_a = [&](int buf, int lo) -> unsigned short* { return cs_lds + (buf * 2 + lo) * CS_A_IMG; };
@@ -40,16 +46,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stage_once_kernel(ConvStageDim
     // zero rows of the four B images
     for (int i = tid; i < 4 * CS_BLD; i += 512) (cs_lds + 4 * CS_A_IMG + (i / CS_BLD) * CS_B_IMG + CS_ROWS * CS_BLD)[i % CS_BLD] = 0;
 
-    // ---- A staging (pre-split weight words, k-fast): two octets per thread ----
-    int a_row[2], a_off[2];
-    const float* a_src[2];
+    // ---- A staging by LDS-DMA: a wave-instruction fills 64 consecutive 16-byte chunks of an image = 16 rows x 4 octets;
+    // wave w takes chunks [(2*i + ...)]: instruction i of wave w covers chunks (i*8 + w)*64 .. +63.  LDS chunk (row, pos)
+    // holds source octet pos ^ xs_swz(row).
+    const int64_t plane = (int64_t)9 * d.M * d.C;             // elements per plane (hi | lo)
+    int a_src[2];                                              // element offset inside one tap's [M][C] matrix
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        a_row[i] = (tid >> 2) + 128 * i;
-        const int oct = tid & 3;
-        a_off[i] = a_row[i] * XS_LD + 8 * (oct ^ xs_swz(a_row[i]));
-        const int m = m0 + a_row[i];
-        a_src[i] = wsplit + (int64_t)(m < d.M ? m : d.M - 1) * d.C + 8 * oct;        // + tap*M*C + k0 per step
+        const int chunk = (i * 8 + wave) * 64 + lane;
+        const int row = chunk >> 2, oct = (chunk & 3) ^ xs_swz(row);
+        const int m = m0 + row;
+        a_src[i] = (m < d.M ? m : d.M - 1) * d.C + 8 * oct;    // + tap*M*C + k0 per step
     }
     // ---- B staging (activations, pixel-fast): row = staged pixel, two octets (8 channels each) per thread ----
     const int b_row = tid & 255;
@@ -63,11 +70,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stage_once_kernel(ConvStageDim
         b_src = x + (int64_t)r * roi_stride + p;
         b_oct[0] = tid >> 8; b_oct[1] = (tid >> 8) + 2;
     }
-    float ra[2][8], rb[2][8];
-    auto fetch_a = [&](int step) {
+    float rb[2][8];
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    auto dma_a = [&](int step, int buf) {
         const int tap = step % 9, k0 = (step / 9) * 32;
+        const unsigned short* base = wplanes + (int64_t)tap * d.M * d.C + k0;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) ld8_contig(a_src[i] + (int64_t)tap * d.M * d.C + k0, ra[i]);
+        for (int i = 0; i < 2; ++i) {
+            const int dst = (i * 8 + wave) * 64 * 8;            // wave-uniform element offset of the 1-KB piece
+            __builtin_amdgcn_global_load_lds(base + a_src[i], (lds_ptr_t)(img_a(buf, 0) + dst), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(base + plane + a_src[i], (lds_ptr_t)(img_a(buf, 1) + dst), 16, 0, 0);
+        }
     };
     auto fetch_b = [&](int slice) {
 #pragma unroll
@@ -75,15 +88,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stage_once_kernel(ConvStageDim
             const float* q = b_src + (int64_t)(slice * 32 + 8 * b_oct[i]) * 49;
 #pragma unroll
             for (int j = 0; j < 8; ++j) rb[i][j] = q[j * 49];
-        }
-    };
-    auto stash_a = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            bf16x8 hi, lo;
-            unpack8(ra[i], hi, lo);
-            *reinterpret_cast<bf16x8*>(img_a(buf, 0) + a_off[i]) = hi;
-            *reinterpret_cast<bf16x8*>(img_a(buf, 1) + a_off[i]) = lo;
         }
     };
     auto stash_b = [&](int buf) {
@@ -149,29 +153,28 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stage_once_kernel(ConvStageDim
         }
     };
 
-    // ---- pipeline: A double-buffered per step (tap inner), B double-buffered per 9-step slice ----
+    // ---- pipeline: A by LDS-DMA, double-buffered per step (tap inner); B double-buffered per 9-step slice ----
     fetch_b(0);
-    fetch_a(0);
     stash_b(0);
-    stash_a(0);
+    dma_a(0, 0);
     if (nslices > 1) fetch_b(1);
-    if (nsteps > 1) fetch_a(1);
-    __syncthreads();
+    __syncthreads();                                    // vmcnt(0): step 0's weights have landed
     int abuf = 0;
     for (int s = 0; s < nsteps; ++s) {
         const int tap = s % 9, slice = s / 9;
-        if (s + 1 < nsteps) stash_a(abuf ^ 1);
-        if (s + 2 < nsteps) fetch_a(s + 2);
-        if (tap == 8 && slice + 1 < nslices) {          // the next slice's activations: held in registers since tap 0
-            stash_b((slice + 1) & 1);
-            if (slice + 2 < nslices) fetch_b(slice + 2);
-        }
+        const bool next_b = tap == 8 && slice + 1 < nslices;
+        // the activation registers (loaded nine steps ago) are consumed BEFORE this step's DMA goes out: the compiler
+        // waits vmcnt(0) at a use of an ordinary load's result while an LDS-DMA is outstanding
+        if (next_b && !(d.dbg & 4)) stash_b((slice + 1) & 1);
+        if (s + 1 < nsteps && !(d.dbg & 8)) dma_a(s + 1, abuf ^ 1);     // the other buffer: its readers passed the last barrier
+        if (next_b && slice + 2 < nslices && !(d.dbg & 4)) fetch_b(slice + 2);
         __builtin_amdgcn_sched_barrier(0);
-        mma(abuf, slice & 1, tap);
-        __syncthreads();
+        if (!(d.dbg & 2)) mma(abuf, slice & 1, tap);
+        __syncthreads();                                // retires the DMA (vmcnt(0)) and frees buffer abuf
         abuf ^= 1;
     }
 
+    if (d.dbg & 1) { if (acc[0][0][0] == 123.456f) epi.store_rb(0, 0, 0, acc[1][1][1], true, 0.f); return; }
     // ---- epilogue: D layout lane -> column l15, rows 4*lq + r (as the 256x224 kernel) ----
     float rbias[4][4];
 #pragma unroll
@@ -198,8 +201,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stage_once_kernel(ConvStageDim
 // -> true when the stage-once kernel ran (C a multiple of 32, at least one full tile of pixels; ARFE_CONV_STAGE_ONCE=0
 // switches it off), false to use the generic GEMM
 template <class EPI>
-static inline bool launch_conv_stage_once(int R, int C, const float* wsplit, const float* x, int64_t roi_stride, EPI epi,
-                                          hipStream_t stream, int32_t* rc) {
+static inline bool launch_conv_stage_once(int R, int C, const unsigned short* wplanes, const float* x, int64_t roi_stride,
+                                          EPI epi, hipStream_t stream, int32_t* rc) {
     static const char* sw = getenv("ARFE_CONV_STAGE_ONCE");
     *rc = ARFE_OK;
     const int N = R * 49;
@@ -211,9 +214,10 @@ static inline bool launch_conv_stage_once(int R, int C, const float* wsplit, con
         *rc = ARFE_ERR_LAUNCH;
         return true;
     }
-    ConvStageDims d{C, N, C, cdiv(N, CS_BN)};      // a ragged last tile: clamped loads, columns >= N are never stored
+    static const int dbg = []() { const char* e = getenv("ARFE_CONV_DBG"); return e ? atoi(e) : 0; }();
+    ConvStageDims d{C, N, C, cdiv(N, CS_BN), dbg};      // a ragged last tile: clamped loads, columns >= N are never stored
     hipLaunchKernelGGL((conv3x3_stage_once_kernel<EPI>), dim3(d.tiles_n, cdiv(C, XL_BM)), dim3(512), CS_LDS_BYTES, stream, d,
-                       wsplit, x, roi_stride, epi);
+                       wplanes, x, roi_stride, epi);
     if (hipGetLastError() != hipSuccess) { set_error("conv3x3 stage-once launch failed"); *rc = ARFE_ERR_LAUNCH; }
     return true;
 }

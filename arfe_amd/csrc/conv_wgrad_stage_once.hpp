@@ -26,7 +26,7 @@ constexpr int WS_ZERO = WS_B_IMG + 16 * WS_B_LD + 8; // zero region: a lane that
                                                      // constant offsets as from an image
 constexpr int WS_LDS_BYTES = (2 * WS_BUF + WS_ZERO) * 2;
 
-struct WgradStageDims { int R, C, rows_total, rows_per_slice, tiles_ci; };
+struct WgradStageDims { int R, C, rows_total, rows_per_slice, tiles_ci, dbg; };   // dbg: probe switches (ARFE_CONV_DBG)
 
 __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_stage_once_kernel(WgradStageDims d, const float* __restrict__ x,
                                                                           int64_t x_roi_stride, const float* __restrict__ dy,
@@ -201,15 +201,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_stage_once_kernel(WgradS
     __syncthreads();
     int buf = 0;
     for (int s = 0; s < nsteps; ++s) {
-        if (s + 1 < nsteps) stash(buf ^ 1);
-        if (s + 2 < nsteps) fetch(s + 2);
+        if (s + 1 < nsteps && !(d.dbg & 4)) stash(buf ^ 1);
+        if (s + 2 < nsteps && !(d.dbg & 4)) fetch(s + 2);
         __builtin_amdgcn_sched_barrier(0);
-        mma(buf, s);
+        if (!(d.dbg & 2)) mma(buf, s);
         __syncthreads();
         buf ^= 1;
     }
 
     if (db && ci0 == 0) unsafeAtomicAdd(db + co0 + a_co, bias_sum);
+    if (d.dbg & 1) { if (acc[0][0][0][0] == 123.456f) dwp[0] = acc[1][1][1][1]; return; }
     // ---- epilogue: D layout lane -> column l15 (ci), rows 4*lq + r (co) ----
 #pragma unroll
     for (int t = 0; t < 9; ++t)
@@ -241,7 +242,8 @@ static inline bool launch_conv_wgrad_stage_once(int R, int C, const float* x, in
         return true;
     }
     WgradStageDims d;
-    d.R = R; d.C = C; d.rows_total = R * 7; d.tiles_ci = C / WS_CI;
+    static const int dbg = []() { const char* e = getenv("ARFE_CONV_DBG"); return e ? atoi(e) : 0; }();
+    d.R = R; d.C = C; d.rows_total = R * 7; d.tiles_ci = C / WS_CI; d.dbg = dbg;
     const int tiles = (C / WS_CO) * d.tiles_ci;
     int nslices = 256 / tiles;
     if (nslices < 1) nslices = 1;

@@ -82,10 +82,17 @@ __device__ __forceinline__ void stage8(const float (&v)[8], bf16x8& hi, bf16x8& 
     else split8(v, hi, lo);
 }
 
+// Pipeline (round 2): two LDS buffers (2 x 32 KB, dynamic) and ONE barrier per K-step, as in the 256-wide kernels below:
+// iteration s splits + stores step s+1 into the other buffer, re-issues the global loads of step s+2 into the registers
+// just freed, then runs the 24 MFMAs of step s.  The first form (one buffer: loads -> MFMAs -> barrier -> split/store ->
+// barrier) exposed the load latency and the whole staging pass every step: 1.8 us per K-step for 0.35 us of MFMAs.
+constexpr int XM_BUF = 4 * GEMM_BM * XS_LD;                 // bf16 elements per buffer: A_hi A_lo B_hi B_lo
+constexpr int XM_LDS_BYTES = 2 * XM_BUF * 2;                // 65 536
+
 template <class LA, class LB, class EPI>
 __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmDims d, LA la, LB lb, EPI epi) {
-    // [operand image: 0 A_hi, 1 A_lo, 2 B_hi, 3 B_lo][row][k]
-    __shared__ __attribute__((aligned(16))) unsigned short lds[4][GEMM_BM][XS_LD];
+    extern __shared__ __attribute__((aligned(16))) unsigned short xm_lds[];
+    auto img = [&](int buf, int which) -> unsigned short* { return xm_lds + (size_t)buf * XM_BUF + which * (GEMM_BM * XS_LD); };
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -127,13 +134,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmDims d, LA la, 
     }
     typename LA::Row arow[2];
     typename LB::Row brow[2];
-    int a_so[2], b_so[2];
+    int a_off[2], b_off[2];          // swizzled element offsets of this thread's staging octets inside an image (xs_swz)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         arow[i] = la.row(z, m0 + a_row[i]);
         brow[i] = lb.row(z, n0 + b_row[i]);
-        a_so[i] = 8 * (a_oct[i] ^ xs_swz(a_row[i]));      // swizzled octet inside the 64-byte LDS row (see xs_swz)
-        b_so[i] = 8 * (b_oct[i] ^ xs_swz(b_row[i]));
+        a_off[i] = a_row[i] * XS_LD + 8 * (a_oct[i] ^ xs_swz(a_row[i]));
+        b_off[i] = b_row[i] * XS_LD + 8 * (b_oct[i] ^ xs_swz(b_row[i]));
     }
     float ra[2][8], rb[2][8];
     auto fetch = [&](int step) {
@@ -154,59 +161,118 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmDims d, LA la, 
             for (int i = 0; i < 2; ++i) lb.template load8<false>(brow[i], z, kb, k0 + 8 * b_oct[i], rb[i]);
         }
     };
-    auto stash = [&]() {
+    // branch-free steady-state loaders (K a multiple of the K-step): the (k-batch, inner step) pair of the step being
+    // fetched is carried and advanced with selects, so the loop body is one scheduling region
+    int f_kb = 0, f_ks = 0;
+    auto fetch_seek = [&](int step) {
+        f_kb = d.kb_inner ? step % d.kb_count : step / ksteps_per_kb;
+        f_ks = d.kb_inner ? step / d.kb_count : step - f_kb * ksteps_per_kb;
+    };
+    auto fetch_full_a = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) la.template load8<true>(arow[i], z, f_kb, f_ks * XB_BK + 8 * a_oct[i], ra[i]);
+    };
+    auto fetch_full_b = [&]() {
+        const int kb = f_kb, k0 = f_ks * XB_BK;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) lb.template load8<true>(brow[i], z, kb, k0 + 8 * b_oct[i], rb[i]);
+        const int inner = d.kb_inner;
+        int kb2 = f_kb + inner, ks2 = f_ks + 1 - inner;
+        const bool wrap_kb = kb2 == d.kb_count;               // only reachable with kb_inner
+        ks2 += (inner & (wrap_kb ? 1 : 0));
+        kb2 = wrap_kb ? 0 : kb2;
+        const bool wrap_ks = (inner == 0) & (ks2 == ksteps_per_kb);
+        kb2 += wrap_ks ? 1 : 0;
+        ks2 = wrap_ks ? 0 : ks2;
+        f_kb = kb2; f_ks = ks2;
+    };
+    auto stash_a = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             bf16x8 hi, lo;
             stage8<LA>(ra[i], hi, lo);
-            *reinterpret_cast<bf16x8*>(&lds[0][a_row[i]][a_so[i]]) = hi;
-            *reinterpret_cast<bf16x8*>(&lds[1][a_row[i]][a_so[i]]) = lo;
-            stage8<LB>(rb[i], hi, lo);
-            *reinterpret_cast<bf16x8*>(&lds[2][b_row[i]][b_so[i]]) = hi;
-            *reinterpret_cast<bf16x8*>(&lds[3][b_row[i]][b_so[i]]) = lo;
+            *reinterpret_cast<bf16x8*>(img(buf, 0) + a_off[i]) = hi;
+            *reinterpret_cast<bf16x8*>(img(buf, 1) + a_off[i]) = lo;
         }
+    };
+    auto stash_b = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            bf16x8 hi, lo;
+            stage8<LB>(rb[i], hi, lo);
+            *reinterpret_cast<bf16x8*>(img(buf, 2) + b_off[i]) = hi;
+            *reinterpret_cast<bf16x8*>(img(buf, 3) + b_off[i]) = lo;
+        }
+    };
+    const int kh = lane >> 5, l31 = lane & 31;
+    const int fsw = xs_swz(l31);     // fragment row bases are multiples of 32
+    auto mma = [&](int buf, int kk) {
+        bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int ar = wm * 64 + t * 32 + l31, br = wn * 64 + t * 32 + l31;
+            const int ko = 8 * (((kk >> 3) + kh) ^ fsw);
+            ah[t] = *reinterpret_cast<const bf16x8*>(img(buf, 0) + ar * XS_LD + ko);
+            al[t] = *reinterpret_cast<const bf16x8*>(img(buf, 1) + ar * XS_LD + ko);
+            bh[t] = *reinterpret_cast<const bf16x8*>(img(buf, 2) + br * XS_LD + ko);
+            bl[t] = *reinterpret_cast<const bf16x8*>(img(buf, 3) + br * XS_LD + ko);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+            }
     };
 
     if (s_begin < s_end) {
         fetch(s_begin);
-        stash();
+        stash_a(0);
+        stash_b(0);
+        if (s_begin + 1 < s_end) fetch(s_begin + 1);
         __syncthreads();
-        const int kh = lane >> 5, l31 = lane & 31;
-        const int fsw = xs_swz(l31);     // fragment row bases are multiples of 32
-        for (int s = s_begin; s < s_end; ++s) {
-            const bool more = (s + 1 < s_end);
-            if (more) fetch(s + 1);
-#pragma unroll
-            for (int kk = 0; kk < XB_BK; kk += 16) {
-                bf16x8 ah[2], al[2], bh[2], bl[2];
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const int ar = wm * 64 + t * 32 + l31, br = wn * 64 + t * 32 + l31;
-                    ah[t] = *reinterpret_cast<const bf16x8*>(&lds[0][ar][8 * (((kk >> 3) + kh) ^ fsw)]);
-                    al[t] = *reinterpret_cast<const bf16x8*>(&lds[1][ar][8 * (((kk >> 3) + kh) ^ fsw)]);
-                    bh[t] = *reinterpret_cast<const bf16x8*>(&lds[2][br][8 * (((kk >> 3) + kh) ^ fsw)]);
-                    bl[t] = *reinterpret_cast<const bf16x8*>(&lds[3][br][8 * (((kk >> 3) + kh) ^ fsw)]);
-                }
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                    }
-            }
-            __syncthreads();            // every wave is done reading this step's images
-            if (more) {
-                stash();
+        int buf = 0;
+        int s = s_begin;
+        if (d.K % XB_BK == 0) {
+            fetch_seek(s + 2);
+            for (; s + 2 < s_end; ++s) {
+                stash_a(buf ^ 1);
+                fetch_full_a();
+                __builtin_amdgcn_sched_barrier(0);
+                mma(buf, 0);
+                stash_b(buf ^ 1);
+                fetch_full_b();
+                __builtin_amdgcn_sched_barrier(0);
+                mma(buf, 16);
                 __syncthreads();
+                buf ^= 1;
             }
+        } else {
+            for (; s + 2 < s_end; ++s) {       // K tail somewhere: the bound-checked loaders (branches in the body)
+                stash_a(buf ^ 1);
+                mma(buf, 0);
+                stash_b(buf ^ 1);
+                fetch(s + 2);
+                mma(buf, 16);
+                __syncthreads();
+                buf ^= 1;
+            }
+        }
+        for (; s < s_end; ++s) {       // last two steps: nothing left to fetch
+            const bool more = s + 1 < s_end;
+            if (more) { stash_a(buf ^ 1); stash_b(buf ^ 1); }
+            mma(buf, 0);
+            mma(buf, 16);
+            __syncthreads();
+            buf ^= 1;
         }
     } else if (!first_split) {
         return;
     }
 
-    const int h = lane >> 5, l31 = lane & 31;
+    const int h = lane >> 5;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1015,7 +1081,13 @@ static inline int32_t launch_gemm_auto(int M, int N, int K, int kb_count, int ba
     d.splitk = splitk;
     d.tiles_m = cdiv(M, GEMM_BM); d.tiles_n = cdiv(N, GEMM_BN);
     dim3 grid(d.tiles_m * d.tiles_n, splitk, batch);
-    hipLaunchKernelGGL((gemm_bf16x3_kernel<LA, LB, EPI>), grid, dim3(256), 0, stream, d, la, lb, epi);
+    static DeviceOnce attr_mid;        // per instantiation and per device
+    if (!attr_mid.run([]() { return hipFuncSetAttribute((const void*)gemm_bf16x3_kernel<LA, LB, EPI>,
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, XM_LDS_BYTES) == hipSuccess; })) {
+        set_error("gemm: cannot reserve %d bytes of LDS", XM_LDS_BYTES);
+        return ARFE_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL((gemm_bf16x3_kernel<LA, LB, EPI>), grid, dim3(256), XM_LDS_BYTES, stream, d, la, lb, epi);
     ARFE_CHECK_LAUNCH();
     return ARFE_OK;
 }

@@ -170,8 +170,10 @@ struct WgradB {        // B(n=ci, k') for tap z: x[r*roi_stride + ci*49 + (py+dy
 
 // w [Cout,Cin,3,3] -> wp[tap][co][ci] (fwd) or wd[tap][ci][co] = w[co][ci][8-tap] (transposed + flipped, dgrad)
 // presplit: the elements are stored as (bf16 hi << 16 | bf16 lo) words for LoadSplitK (bf16x3 mode), else as floats
+// planes (bf16x3 mode): the same two matrices once more as bf16 PLANES - ph = [hi plane 9*C*C | lo plane 9*C*C] of wp,
+// pd likewise of wd - the form the stage-once conv kernel copies to LDS by LDS-DMA
 __global__ void conv_w_permute_kernel(const float* __restrict__ w, float* __restrict__ wp, float* __restrict__ wd, int C,
-                                      int presplit) {
+                                      int presplit, unsigned short* __restrict__ ph, unsigned short* __restrict__ pd) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     int total = C * C * 9;
     if (i >= total) return;
@@ -180,8 +182,11 @@ __global__ void conv_w_permute_kernel(const float* __restrict__ w, float* __rest
     float f = w[((int64_t)a * C + b) * 9 + tap];           // wp[tap][co=a][ci=b]
     float g = w[((int64_t)b * C + a) * 9 + (8 - tap)];     // wd[tap][ci=a][co=b]
     if (presplit) {
-        f = __uint_as_float(presplit_word(f));
-        g = __uint_as_float(presplit_word(g));
+        const unsigned fw = presplit_word(f), gw = presplit_word(g);
+        ph[i] = (unsigned short)(fw >> 16); ph[total + i] = (unsigned short)(fw & 0xffffu);
+        pd[i] = (unsigned short)(gw >> 16); pd[total + i] = (unsigned short)(gw & 0xffffu);
+        f = __uint_as_float(fw);
+        g = __uint_as_float(gw);
     }
     wp[i] = f;
     wd[i] = g;
@@ -507,8 +512,9 @@ extern "C" int32_t arfe_linear_bwd(int32_t R, int32_t in_f, int32_t out_f, const
 // 3x3 conv on RoI tiles
 // =========================================================================================================
 extern "C" int64_t arfe_conv3x3_packed_bytes(int32_t C) {
-    // wp[tap][co][ci] followed by wd[tap][ci][co] (flipped/transposed for the data gradient)
-    return (int64_t)2 * 9 * C * C * sizeof(float);
+    // wp[tap][co][ci] followed by wd[tap][ci][co] (flipped/transposed for the data gradient), then the same two matrices
+    // as bf16 (hi plane | lo plane) for the LDS-DMA staging of the stage-once kernels
+    return (int64_t)4 * 9 * C * C * sizeof(float);
 }
 extern "C" int64_t arfe_conv3x3_workspace_bytes(int32_t C) {
     return (int64_t)9 * C * C * sizeof(float);   // permuted weight-gradient accumulator
@@ -519,8 +525,10 @@ extern "C" int32_t arfe_conv3x3_pack_weights(int32_t C, const float* w, void* pa
     float* wp = (float*)packed;
     float* wd = wp + (size_t)9 * C * C;
     int total = 9 * C * C;
+    unsigned short* ph = (unsigned short*)(wd + (size_t)9 * C * C);
+    unsigned short* pd = ph + (size_t)2 * 9 * C * C;
     hipLaunchKernelGGL(conv_w_permute_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), w, wp, wd, C,
-                       gemm_use_f32() ? 0 : 1);
+                       gemm_use_f32() ? 0 : 1, ph, pd);
     ARFE_CHECK_LAUNCH();
     return ARFE_OK;
 }
@@ -537,7 +545,8 @@ extern "C" int32_t arfe_conv3x3_fwd(int32_t R, int32_t C, const float* x, int64_
     EpiConv e{y, y_roi_stride, b, relu, nullptr, 0};
     {
         int32_t rc_so;
-        if (launch_conv_stage_once(R, C, wp, x, x_roi_stride, e, as_stream(stream), &rc_so)) return rc_so;
+        const unsigned short* ph = (const unsigned short*)(wp + (size_t)2 * 9 * C * C);
+        if (launch_conv_stage_once(R, C, ph, x, x_roi_stride, e, as_stream(stream), &rc_so)) return rc_so;
     }
     return launch_gemm_auto(C, R * 49, C, 9, 1, 1, la, lb, e, as_stream(stream), /*exact=*/false, /*kb_inner=*/true);
 }
@@ -555,7 +564,8 @@ extern "C" int32_t arfe_conv3x3_bwd_data(int32_t R, int32_t C, const void* packe
     EpiConv e{dx, dx_roi_stride, nullptr, 0, dx_mask, dx_mask_roi_stride};
     {
         int32_t rc_so;
-        if (launch_conv_stage_once(R, C, wd, dy, dy_roi_stride, e, as_stream(stream), &rc_so)) return rc_so;
+        const unsigned short* pd = (const unsigned short*)((const float*)packed + (size_t)2 * 9 * C * C) + (size_t)2 * 9 * C * C;
+        if (launch_conv_stage_once(R, C, pd, dy, dy_roi_stride, e, as_stream(stream), &rc_so)) return rc_so;
     }
     return launch_gemm_auto(C, R * 49, C, 9, 1, 1, la, lb, e, as_stream(stream), /*exact=*/false, /*kb_inner=*/true);
 }
