@@ -7,7 +7,9 @@
 //   * x rows once with a one-row halo, in THREE column-shifted copies made in registers before the split
 //     (dx = -1, 0, +1; zeros shifted in): [3][64 ci][6 octets].  A tap's row shift dy is then a whole k-octet
 //     (octet lq + dy + 1 of copy dx + 1) and a lane whose shifted row leaves the RoI reads a zero octet.
-// Partial sums of the row slices are added atomically into the zeroed dWp (as the generic path does).
+// Partial sums of the row slices: every workgroup stores its 9 x 128 x 64 block into ITS slice's slab of the workspace
+// (plain stores) and conv_wgrad_reduce_kernel sums the slabs straight into dw[co][ci][tap] - 75 MB of float atomics into
+// a zeroed dWp took 50 of the kernel's 240 us (tools/probe/conv_dbg.sh), and the sum is now in a fixed order.
 // The bias gradient db[co] = sum_{r, p} dy[r][co][p] rides along: the threads that stage the dy rows of the ci-block-0
 // workgroups add up what they fetch (fp32, before the split) and add their totals to the zeroed db once at the end, so
 // the separate 51 MB reduction pass over dy is not needed.
@@ -219,18 +221,56 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_stage_once_kernel(WgradS
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int n = ci0 + wn * 32 + j * 16 + l15;
+                float* slab = dwp + (int64_t)blockIdx.x * 9 * d.C * d.C;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int m = co0 + wm * 32 + i * 16 + 4 * lq + r;
-                    unsafeAtomicAdd(dwp + ((int64_t)t * d.C + m) * d.C + n, acc[t][i][j][r]);
+                    slab[((int64_t)t * d.C + m) * d.C + n] = acc[t][i][j][r];
                 }
             }
 }
 
-// -> true when the kernel ran (C a multiple of 128, bf16x3 mode, ARFE_CONV_STAGE_ONCE != 0); dwp and db must be zeroed
-// before; db (may be null) receives the bias gradient
+// dw[co][ci][tap] = sum over the slabs of slab[s][tap][co][ci]: four ci per thread (16-byte reads along a slab row)
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ slabs, int nslabs, int C,
+                                                                float* __restrict__ dw) {
+    const int64_t per = (int64_t)9 * C * C;
+    const int64_t q = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (q >= per) return;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 s = {0.f, 0.f, 0.f, 0.f};
+    const float* p = slabs + q;
+    int k = 0;
+    for (; k + 8 <= nslabs; k += 8) {
+        f4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f4*>(p + (int64_t)(k + u) * per);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < nslabs; ++k) s += *reinterpret_cast<const f4*>(p + (int64_t)k * per);
+    const int tap = (int)(q / ((int64_t)C * C));
+    const int64_t pair = q - (int64_t)tap * C * C;          // co * C + ci (C is a multiple of 4: the quad stays in one row)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dw[(pair + e) * 9 + tap] = s[e];
+}
+
+// slabs the launch below will write for (R, C), 0 when the kernel does not apply: the caller sizes the workspace with it
+static inline int conv_wgrad_stage_once_slabs(int R, int C) {
+    if (C % WS_CO != 0 || R < 64) return 0;
+    const int tiles = (C / WS_CO) * (C / WS_CI);
+    int nslices = 256 / tiles;
+    if (nslices < 1) nslices = 1;
+    const int rows_total = R * 7;
+    const int rows_per_slice = ((cdiv(rows_total, nslices) + 3) / 4) * 4;
+    return cdiv(rows_total, rows_per_slice);
+}
+
+// -> true when the kernel ran (C a multiple of 128, bf16x3 mode, ARFE_CONV_STAGE_ONCE != 0): dw is complete (slabs in
+// `dwp`, which must hold conv_wgrad_stage_once_slabs(R, C) x 9 C C floats); db must be zeroed before and receives the
+// bias gradient
 static inline bool launch_conv_wgrad_stage_once(int R, int C, const float* x, int64_t x_roi_stride, const float* dy,
-                                                int64_t dy_roi_stride, float* dwp, float* db, hipStream_t stream, int32_t* rc) {
+                                                int64_t dy_roi_stride, float* dwp, float* dw, float* db, hipStream_t stream,
+                                                int32_t* rc) {
     static const char* sw = getenv("ARFE_CONV_STAGE_ONCE");
     *rc = ARFE_OK;
     if ((sw && sw[0] == '0') || gemm_use_f32() || C % WS_CO != 0 || R < 64) return false;
@@ -251,7 +291,9 @@ static inline bool launch_conv_wgrad_stage_once(int R, int C, const float* x, in
     nslices = cdiv(d.rows_total, d.rows_per_slice);
     hipLaunchKernelGGL(conv3x3_wgrad_stage_once_kernel, dim3(nslices, tiles), dim3(512), WS_LDS_BYTES, stream, d, x, x_roi_stride,
                        dy, dy_roi_stride, dwp, db);
-    if (hipGetLastError() != hipSuccess) { set_error("conv3x3 wgrad stage-once launch failed"); *rc = ARFE_ERR_LAUNCH; }
+    if (hipGetLastError() != hipSuccess) { set_error("conv3x3 wgrad stage-once launch failed"); *rc = ARFE_ERR_LAUNCH; return true; }
+    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(cdiv(9 * C * C / 4, 256)), dim3(256), 0, stream, (const float*)dwp, nslices, C, dw);
+    if (hipGetLastError() != hipSuccess) { set_error("conv3x3 wgrad reduce launch failed"); *rc = ARFE_ERR_LAUNCH; }
     return true;
 }
 

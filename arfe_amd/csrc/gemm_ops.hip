@@ -517,7 +517,10 @@ extern "C" int64_t arfe_conv3x3_packed_bytes(int32_t C) {
     return (int64_t)4 * 9 * C * C * sizeof(float);
 }
 extern "C" int64_t arfe_conv3x3_workspace_bytes(int32_t C) {
-    return (int64_t)9 * C * C * sizeof(float);   // permuted weight-gradient accumulator
+    // permuted weight-gradient accumulator of the generic path, or the per-slice slabs of the stage-once kernel
+    // (256 workgroups x 9 x 128 x 64 floats = 75.5 MB whenever C is a multiple of 128)
+    const int64_t slabs = C % WS_CO == 0 ? (int64_t)(256 / ((C / WS_CO) * (C / WS_CI)) > 0 ? 256 / ((C / WS_CO) * (C / WS_CI)) : 1) : 1;
+    return slabs * 9 * C * C * (int64_t)sizeof(float);
 }
 
 extern "C" int32_t arfe_conv3x3_pack_weights(int32_t C, const float* w, void* packed, void* stream) {
@@ -584,10 +587,12 @@ extern "C" int32_t arfe_conv3x3_bwd_weight(int32_t R, int32_t C, const float* x,
     ARFE_CHECK_ARG(x && dy && workspace, ARFE_ERR_ARG, "conv3x3_bwd_weight: null pointer");
     float* dwp = (float*)workspace;
     int total = 9 * C * C;
+    static const char* so_sw = getenv("ARFE_CONV_STAGE_ONCE");
+    const bool stage_once = !(so_sw && so_sw[0] == '0') && !gemm_use_f32() && conv_wgrad_stage_once_slabs(R, C) > 0;
     {
         ZeroList z;
         z.add(db, C);
-        z.add(dwp, total);
+        if (!stage_once) z.add(dwp, total);           // the stage-once kernel stores whole slabs: nothing to pre-zero
         int32_t zr = zero_buffers(z, st);
         if (zr) return zr;
     }
@@ -602,10 +607,10 @@ extern "C" int32_t arfe_conv3x3_bwd_weight(int32_t R, int32_t C, const float* x,
     EpiPlain e = epi_plain(dwp, (int64_t)C * C, C);
     e.atomic = 1;
     int32_t rc;
-    bool db_done = false;
-    if (launch_conv_wgrad_stage_once(R, C, x, x_roi_stride, dy, dy_roi_stride, dwp, db, st, &rc)) {
-        // (the nine taps in one kernel, operands staged once per pixel chunk: conv_wgrad_stage_once.hpp; it also sums db)
-        db_done = true;
+    if (stage_once && launch_conv_wgrad_stage_once(R, C, x, x_roi_stride, dy, dy_roi_stride, dwp, dw, db, st, &rc)) {
+        // (the nine taps in one kernel, operands staged once per pixel chunk: conv_wgrad_stage_once.hpp; it also sums db
+        // and its slab reduction writes dw in the parameter's layout)
+        return rc;
     } else if (zvar) {
         GemmDims zv;
         const int tiles = cdiv(C, XL_BM) * cdiv(C, XL_BN);
@@ -651,12 +656,10 @@ extern "C" int32_t arfe_conv3x3_bwd_weight(int32_t R, int32_t C, const float* x,
     if (rc) return rc;
     hipLaunchKernelGGL(conv_dw_unpermute_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, dwp, dw, C);
     ARFE_CHECK_LAUNCH();
-    if (!db_done) {
-        int chunk = 64;
-        dim3 grid(C, cdiv(R, chunk));
-        hipLaunchKernelGGL(reduce_mid_kernel, grid, dim3(256), 0, st, dy, (const float*)nullptr, db, R, dy_roi_stride, 49, chunk);
-        ARFE_CHECK_LAUNCH();
-    }
+    int chunk = 64;
+    dim3 grid(C, cdiv(R, chunk));
+    hipLaunchKernelGGL(reduce_mid_kernel, grid, dim3(256), 0, st, dy, (const float*)nullptr, db, R, dy_roi_stride, 49, chunk);
+    ARFE_CHECK_LAUNCH();
     return ARFE_OK;
 }
 
