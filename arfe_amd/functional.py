@@ -477,6 +477,94 @@ def rff_prepack(w_wh, w_hh, w_f):
     return on_side(ws[0].device, lambda: tuple(conv3x3_pack_op(w) for w in ws))
 
 
+def _rff_head_forward(x, params, packs):
+    """MultiBBoxHead.forward on contiguous fp32 tensors -> (cls, reg, saved tensors for _rff_head_backward).
+    packs: (pk_wh, pk_hh, pk_f) already ordered before the current stream, or None (packed here)."""
+    w_wh, b_wh, w_hh, b_hh, w_f, b_f, w1, b1, w2, b2, wc, bc, wr, br = params
+    R, C3 = x.shape[0], x.shape[1]
+    C = C3 // 3
+    assert C3 == 3 * C and x.shape[2:] == (7, 7), "AR-RFF head expects [R, 3C, 7, 7]"
+    if packs is None:
+        pk_wh, pk_hh, pk_f = conv3x3_pack_op(w_wh), conv3x3_pack_op(w_hh), conv3x3_pack_op(w_f)
+    else:
+        pk_wh, pk_hh, pk_f = packs
+    rs = C3 * 49
+    base = x.data_ptr()
+    # the two gating convs are independent: two 224-workgroup launches side by side pack the 256 CUs
+    lh = on_side(x.device, lambda: conv3x3_fwd_op(base + 4 * 2 * C * 49, rs, R, C, pk_hh, b_hh, True))
+    lw = conv3x3_fwd_op(base + 4 * C * 49, rs, R, C, pk_wh, b_wh, True)
+    join_side(x.device)
+    z = torch.empty(R, C, 7, 7, device=x.device)
+    check(hip.lib().arfe_rff_fuse_fwd(R, C, base, rs, ptr(lw), ptr(lh), ptr(z), stream()), "arfe_rff_fuse_fwd")
+    z2 = conv3x3_fwd_op(z.data_ptr(), C * 49, R, C, pk_f, b_f, True)
+    f1 = linear_fwd_op(z2.view(R, C * 49), w1, b1, True)
+    f2 = linear_fwd_op(f1, w2, b2, True)
+    # the two predictors are small, latency-bound and independent: side by side
+    reg = on_side(x.device, lambda: linear_fwd_op(f2, wr, br, False))
+    cls = linear_fwd_op(f2, wc, bc, False)
+    join_side(x.device)
+    return cls, reg, (x, w_wh, w_hh, w_f, w1, w2, wc, wr, lw, lh, z, z2, f1, f2, pk_wh, pk_hh, pk_f)
+
+
+def _rff_head_backward(saved, dcls, dreg, join=True, defer_gate_wgrads=False):
+    """-> (dx [R,3C,7,7], 14 parameter gradients in forward-argument order, keep-alive tensors[, late]).
+    defer_gate_wgrads: do not launch the weight gradients of wh_conv / hh_conv; `late()` launches them on the side stream
+    (ordered after everything enqueued on the current stream at THAT moment) and fills their four slots of the list.
+    Every ReLU backward is folded into the epilogue of the kernel that PRODUCES the gradient.  Data gradients form the
+    critical chain on the current stream; each parameter gradient is launched on the side stream as soon as its incoming
+    gradient exists.  join=False leaves the side stream (the three conv weight gradients, 0.65 ms of matrix-pipe work
+    nothing downstream reads) running: the caller joins after it has enqueued more data-path work."""
+    x, w_wh, w_hh, w_f, w1, w2, wc, wr, lw, lh, z, z2, f1, f2, pk_wh, pk_hh, pk_f = saved
+    R, C3 = x.shape[0], x.shape[1]
+    C = C3 // 3
+    dev = x.device
+    rs = C3 * 49
+    dcls = dcls.contiguous() if dcls is not None else torch.zeros(R, wc.shape[0], device=dev)
+    dreg = dreg.contiguous() if dreg is not None else torch.zeros(R, wr.shape[0], device=dev)
+    ws = _ws(hip.lib().arfe_conv3x3_workspace_bytes(C), dev)
+    z2f = z2.view(R, C * 49)
+
+    def side_do(fn):
+        return on_side(dev, fn)
+
+    dwc, dbc = side_do(lambda: linear_bwd_weight_op(f2, wc, dcls))
+    dwr, dbr = side_do(lambda: linear_bwd_weight_op(f2, wr, dreg))
+    df2 = linear_bwd_data_op(f2, wc, dcls)
+    linear_bwd_data_op(f2, wr, dreg, dx=df2, accumulate_dx=True, mask_dx_by_x=True)        # df2 *= [f2>0]
+    dw2, db2 = side_do(lambda: linear_bwd_weight_op(f1, w2, df2))
+    df1 = linear_bwd_data_op(f1, w2, df2, mask_dx_by_x=True)                               # df1 *= [f1>0]
+    dw1, db1 = side_do(lambda: linear_bwd_weight_op(z2f, w1, df1))
+    dz2 = linear_bwd_data_op(z2f, w1, df1, mask_dx_by_x=True)                              # dz2 *= [z2>0]
+    dwf, dbf = side_do(lambda: conv3x3_bwd_weight_op(z.data_ptr(), C * 49, R, C, w_f, dz2, ws))
+    dz = torch.empty(R, C, 7, 7, device=dev)
+    conv3x3_bwd_data_op(R, C, pk_f, dz2, dz.data_ptr(), C * 49)
+    dx = torch.empty_like(x)
+    dlw = torch.empty(R, C, 7, 7, device=dev)
+    dlh = torch.empty(R, C, 7, 7, device=dev)
+    check(hip.lib().arfe_rff_fuse_bwd(R, C, x.data_ptr(), rs, ptr(lw), ptr(lh), ptr(dz), dx.data_ptr(), rs, ptr(dlw),
+                                      ptr(dlh), stream()), "arfe_rff_fuse_bwd")
+    # side stream: the two weight gradients back to back; main stream: the two data gradients back to back (each pair
+    # of concurrent kernels fills the CUs the other leaves idle; three kernels in a row on one stream did not)
+    pg = [None, None, None, None, dwf, dbf, dw1, db1, dw2, db2, dwc, dbc, dwr, dbr]
+
+    def gate_wgrads():
+        pg[0], pg[1] = side_do(lambda: conv3x3_bwd_weight_op(x.data_ptr() + 4 * C * 49, rs, R, C, w_wh, dlw, ws))
+        pg[2], pg[3] = side_do(lambda: conv3x3_bwd_weight_op(x.data_ptr() + 8 * C * 49, rs, R, C, w_hh, dlh, ws))
+
+    if not defer_gate_wgrads:
+        gate_wgrads()
+    conv3x3_bwd_data_op(R, C, pk_wh, dlw, dx.data_ptr() + 4 * C * 49, rs)
+    conv3x3_bwd_data_op(R, C, pk_hh, dlh, dx.data_ptr() + 8 * C * 49, rs)
+    if join:
+        join_side(dev)
+    # (dz2, dz, dlw, dlh, ws are read by side-stream kernels that may still be queued when join=False: they were allocated
+    # on the current stream, whose allocator only re-issues them to work enqueued after the caller's join)
+    keep = (dz2, dz, dlw, dlh, ws, df1, df2)
+    if defer_gate_wgrads:
+        return dx, pg, keep, gate_wgrads
+    return dx, pg, keep
+
+
 class RFFHeadFunction(torch.autograd.Function):
     """MultiBBoxHead.forward (num_shared_fcs=2): x [R,3C,7,7] -> (cls_score, bbox_pred).
     args: x, w_wh, b_wh, w_hh, b_hh, w_f, b_f, w_fc1, b_fc1, w_fc2, b_fc2, w_cls, b_cls, w_reg, b_reg,
@@ -487,80 +575,91 @@ class RFFHeadFunction(torch.autograd.Function):
                 pk_f=None):
         x = x.contiguous()
         params = [p.contiguous() for p in (w_wh, b_wh, w_hh, b_hh, w_f, b_f, w1, b1, w2, b2, wc, bc, wr, br)]
-        w_wh, b_wh, w_hh, b_hh, w_f, b_f, w1, b1, w2, b2, wc, bc, wr, br = params
         hip.require_f32_cuda(x, *params)
-        R, C3 = x.shape[0], x.shape[1]
-        C = C3 // 3
-        assert C3 == 3 * C and x.shape[2:] == (7, 7), "AR-RFF head expects [R, 3C, 7, 7]"
-        if pk_wh is None:
-            pk_wh, pk_hh, pk_f = conv3x3_pack_op(w_wh), conv3x3_pack_op(w_hh), conv3x3_pack_op(w_f)
-        else:
+        packs = None
+        if pk_wh is not None:
             join_side(x.device)          # the packs were launched on the side stream
-        rs = C3 * 49
-        base = x.data_ptr()
-        # the two gating convs are independent: two 196-workgroup launches side by side pack the 256 CUs
-        lh = on_side(x.device, lambda: conv3x3_fwd_op(base + 4 * 2 * C * 49, rs, R, C, pk_hh, b_hh, True))
-        lw = conv3x3_fwd_op(base + 4 * C * 49, rs, R, C, pk_wh, b_wh, True)
-        join_side(x.device)
-        z = torch.empty(R, C, 7, 7, device=x.device)
-        check(hip.lib().arfe_rff_fuse_fwd(R, C, base, rs, ptr(lw), ptr(lh), ptr(z), stream()), "arfe_rff_fuse_fwd")
-        z2 = conv3x3_fwd_op(z.data_ptr(), C * 49, R, C, pk_f, b_f, True)
-        f1 = linear_fwd_op(z2.view(R, C * 49), w1, b1, True)
-        f2 = linear_fwd_op(f1, w2, b2, True)
-        # the two predictors are small, latency-bound and independent: side by side
-        reg = on_side(x.device, lambda: linear_fwd_op(f2, wr, br, False))
-        cls = linear_fwd_op(f2, wc, bc, False)
-        join_side(x.device)
-        ctx.save_for_backward(x, w_wh, w_hh, w_f, w1, w2, wc, wr, lw, lh, z, z2, f1, f2, pk_wh, pk_hh, pk_f)
+            packs = (pk_wh, pk_hh, pk_f)
+        cls, reg, saved = _rff_head_forward(x, params, packs)
+        ctx.save_for_backward(*saved)
         return cls, reg
 
     @staticmethod
     def backward(ctx, dcls, dreg):
-        x, w_wh, w_hh, w_f, w1, w2, wc, wr, lw, lh, z, z2, f1, f2, pk_wh, pk_hh, pk_f = ctx.saved_tensors
-        R, C3 = x.shape[0], x.shape[1]
-        C = C3 // 3
-        dev = x.device
-        rs = C3 * 49
-        dcls = dcls.contiguous() if dcls is not None else torch.zeros(R, wc.shape[0], device=dev)
-        dreg = dreg.contiguous() if dreg is not None else torch.zeros(R, wr.shape[0], device=dev)
-        ws = _ws(hip.lib().arfe_conv3x3_workspace_bytes(C), dev)
-        # Every ReLU backward is folded into the epilogue of the kernel that PRODUCES the gradient.
-        # Data gradients form the critical chain on the current stream; each parameter gradient is launched on the
-        # side stream as soon as its incoming gradient exists.
-        z2f = z2.view(R, C * 49)
-
-        def side_do(fn):
-            return on_side(dev, fn)
-
-        dwc, dbc = side_do(lambda: linear_bwd_weight_op(f2, wc, dcls))
-        dwr, dbr = side_do(lambda: linear_bwd_weight_op(f2, wr, dreg))
-        df2 = linear_bwd_data_op(f2, wc, dcls)
-        linear_bwd_data_op(f2, wr, dreg, dx=df2, accumulate_dx=True, mask_dx_by_x=True)        # df2 *= [f2>0]
-        dw2, db2 = side_do(lambda: linear_bwd_weight_op(f1, w2, df2))
-        df1 = linear_bwd_data_op(f1, w2, df2, mask_dx_by_x=True)                               # df1 *= [f1>0]
-        dw1, db1 = side_do(lambda: linear_bwd_weight_op(z2f, w1, df1))
-        dz2 = linear_bwd_data_op(z2f, w1, df1, mask_dx_by_x=True)                              # dz2 *= [z2>0]
-        dwf, dbf = side_do(lambda: conv3x3_bwd_weight_op(z.data_ptr(), C * 49, R, C, w_f, dz2, ws))
-        dz = torch.empty(R, C, 7, 7, device=dev)
-        conv3x3_bwd_data_op(R, C, pk_f, dz2, dz.data_ptr(), C * 49)
-        dx = torch.empty_like(x)
-        dlw = torch.empty(R, C, 7, 7, device=dev)
-        dlh = torch.empty(R, C, 7, 7, device=dev)
-        check(hip.lib().arfe_rff_fuse_bwd(R, C, x.data_ptr(), rs, ptr(lw), ptr(lh), ptr(dz), dx.data_ptr(), rs, ptr(dlw),
-                                          ptr(dlh), stream()), "arfe_rff_fuse_bwd")
-        # side stream: the two weight gradients back to back; main stream: the two data gradients back to back (each pair
-        # of concurrent kernels fills the CUs the other leaves idle; three kernels in a row on one stream did not)
-        dwwh, dbwh = side_do(lambda: conv3x3_bwd_weight_op(x.data_ptr() + 4 * C * 49, rs, R, C, w_wh, dlw, ws))
-        dwhh, dbhh = side_do(lambda: conv3x3_bwd_weight_op(x.data_ptr() + 8 * C * 49, rs, R, C, w_hh, dlh, ws))
-        conv3x3_bwd_data_op(R, C, pk_wh, dlw, dx.data_ptr() + 4 * C * 49, rs)
-        conv3x3_bwd_data_op(R, C, pk_hh, dlh, dx.data_ptr() + 8 * C * 49, rs)
-        join_side(dev)
-        return (dx, dwwh, dbwh, dwhh, dbhh, dwf, dbf, dw1, db1, dw2, db2, dwc, dbc, dwr, dbr, None, None, None)
+        dx, pg, _keep = _rff_head_backward(ctx.saved_tensors, dcls, dreg, join=True)
+        return (dx, *pg, None, None, None)
 
 
 def rff_head(x, w_wh, b_wh, w_hh, b_hh, w_f, b_f, w1, b1, w2, b2, wc, bc, wr, br, packed=None):
     pk = tuple(packed) if packed is not None else (None, None, None)
     return RFFHeadFunction.apply(x, w_wh, b_wh, w_hh, b_hh, w_f, b_f, w1, b1, w2, b2, wc, bc, wr, br, *pk)
+
+
+class RFFExtractHeadFunction(torch.autograd.Function):
+    """The AR-RFF body of `_bbox_forward` as ONE autograd node: 3-set RoIAlign concat (RoIExtractFunction) followed by
+    MultiBBoxHead.forward (RFFHeadFunction) -> (cls_score, bbox_pred, bbox_feats).  Same kernels, same results; what the
+    fusion buys is scheduling the two separate nodes cannot express without breaking autograd's contract that a node's
+    returned gradients are ready on its stream:
+      * backward: the conv / FC weight gradients (matrix-pipe bound, read by nothing downstream) stay on the side stream
+        while the RoIAlign backward (latency bound) runs on the main one; the streams join once, at the end;
+      * forward: weight re-layout and the RoI-only half of the RoIAlign backward run beside the RoIAlign forward.
+    args: strides, pooled, sample_num, nfeat, feat_0..feat_{n-1}, rois, w_rois, h_rois, lv_ori, lv_w, lv_h, 14 head params"""
+
+    @staticmethod
+    def forward(ctx, strides, pooled, sample_num, nfeat, *t):
+        feats = [f.contiguous() for f in t[:nfeat]]
+        roi_sets = [r.contiguous() for r in t[nfeat:nfeat + 3]]
+        levels = [l.contiguous() for l in t[nfeat + 3:nfeat + 6]]
+        params = [p.contiguous() for p in t[nfeat + 6:nfeat + 20]]
+        hip.require_f32_cuda(*feats, *roi_sets, *params)
+        dev = feats[0].device
+        R, C = roi_sets[0].shape[0], feats[0].shape[1]
+        ctx.set_materialize_grads(False)
+        packs = on_side(dev, lambda: tuple(conv3x3_pack_op(w) for w in (params[0], params[2], params[4])))
+        x = torch.empty(R, 3 * C, pooled, pooled, device=dev)
+        prepared, ctx.prep_event = None, None
+        if R > 0:
+            if any(ctx.needs_input_grad[4:4 + nfeat]):
+                prepared = on_side(dev, lambda: roialign_bwd_prepare_op(feats, strides, roi_sets, levels, pooled, sample_num))
+                ctx.prep_event = side_stream(dev).record_event()
+            roialign_fwd_op(feats, strides, roi_sets, levels, x, pooled, sample_num)
+        join_side(dev)                    # packs (and the prepare, long finished) before the first conv
+        cls, reg, saved = _rff_head_forward(x, params, packs)
+        ctx.cfg = (tuple(strides), pooled, sample_num, nfeat)
+        ctx.shapes = [f.shape for f in feats]
+        ctx.has_prepared = prepared is not None
+        ctx.save_for_backward(*saved, *roi_sets, *levels, *([prepared] if prepared is not None else []))
+        return cls, reg, x
+
+    @staticmethod
+    def backward(ctx, dcls, dreg, dfeat):
+        strides, pooled, sample_num, nfeat = ctx.cfg
+        s = ctx.saved_tensors
+        saved, roi_sets, levels = s[:17], list(s[17:20]), list(s[20:23])
+        prepared = s[23] if ctx.has_prepared else None
+        dev = saved[0].device
+        # (Measured: holding the gate convs' weight gradients back until the data-gradient chain is through, so that they
+        # share the chip with the RoIAlign backward only, is SLOWER - that kernel's two contractions run on the fp32 matrix
+        # pipe, and the two kinds of MFMA work just queue: 620 + 549 us side by side against 450 + 2 x 217 alone.)
+        dx, pg, keep = _rff_head_backward(saved, dcls, dreg, join=False)
+        dfeats = [None] * nfeat
+        if any(ctx.needs_input_grad[4:4 + nfeat]):
+            if dfeat is not None:             # a consumer of bbox_feats other than the head (not on the AR path)
+                dx = dx + dfeat
+            if prepared is not None:
+                torch.cuda.current_stream().wait_event(ctx.prep_event)
+            if roi_sets[0].shape[0] > 0:
+                dfeats = roialign_bwd_op(ctx.shapes, strides, roi_sets, levels, dx, pooled, sample_num, prepared)
+            else:
+                dfeats = [torch.zeros(shape, device=dev) for shape in ctx.shapes]
+        join_side(dev)                        # the parameter gradients
+        del keep
+        return (None, None, None, None, *dfeats, None, None, None, None, None, None, *pg)
+
+
+def rff_extract_head(feats, roi_sets, levels, params, strides, pooled=7, sample_num=0):
+    """-> (cls_score, bbox_pred, bbox_feats); roi_sets / levels in concat order (ori, w, h), params as RFFHeadFunction's."""
+    return RFFExtractHeadFunction.apply(tuple(strides), pooled, sample_num, len(feats), *feats, *roi_sets, *levels, *params)
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -161,13 +161,16 @@ class MultiBBoxHead(BBoxHead):
             return None
         return Fn.rff_prepack(*ws)
 
+    def _params(self):
+        return [self.wh_conv.conv.weight, self.wh_conv.conv.bias, self.hh_conv.conv.weight, self.hh_conv.conv.bias,
+                self.final_conv.conv.weight, self.final_conv.conv.bias, self.shared_fcs[0].weight,
+                self.shared_fcs[0].bias, self.shared_fcs[1].weight, self.shared_fcs[1].bias, self.fc_cls.weight,
+                self.fc_cls.bias, self.fc_reg.weight, self.fc_reg.bias]
+
     def forward(self, x, packed=None):
         # no @auto_fp16 on this forward in the reference (multirois_bbox_head.py:165): in fp16 mode x arrives as half
         # from the extractor (out_fp16) and meets half parameters
-        params = [self.wh_conv.conv.weight, self.wh_conv.conv.bias, self.hh_conv.conv.weight, self.hh_conv.conv.bias,
-                  self.final_conv.conv.weight, self.final_conv.conv.bias, self.shared_fcs[0].weight,
-                  self.shared_fcs[0].bias, self.shared_fcs[1].weight, self.shared_fcs[1].bias, self.fc_cls.weight,
-                  self.fc_cls.bias, self.fc_reg.weight, self.fc_reg.bias]
+        params = self._params()
         (x,), p, finish = Fn.f32_boundary([x], params, 'MultiBBoxHead')
         return finish(Fn.rff_head(x, *p, packed=packed if x.dtype == torch.float32 else None))
 
@@ -177,6 +180,33 @@ class MultiRoIsBBoxHead(MultiBBoxHead):
     def __init__(self, fc_out_channels=1024, *args, **kwargs):
         super().__init__(num_shared_convs=0, num_shared_fcs=2, num_cls_convs=0, num_cls_fcs=0, num_reg_convs=0,
                          num_reg_fcs=0, fc_out_channels=fc_out_channels, *args, **kwargs)
+
+
+def ar_rff_bbox_forward(bbox_roi_extractor, bbox_head, x, rois):
+    """The intended AR-RFF body of `_bbox_forward` (standard_roi_head.py:138-155, cascade_roi_head.py:126-135):
+    get_adaptive_scale_rois, three RoIAlign sets, channel concat, MultiBBoxHead -> dict(cls_score, bbox_pred, bbox_feats).
+    In fp32 with the stock extractor / head classes the whole body is one autograd node (Fn.rff_extract_head: same
+    kernels, better stream overlap); otherwise (fp16 mode: the extractor is forced to fp32 and rounds its output to half,
+    subclasses) the extractor and the head run as the two modules they are."""
+    n = bbox_roi_extractor.num_inputs
+    feats = list(x)[:n]
+    fusable = (type(bbox_roi_extractor) is SingleRoIExtractor and isinstance(bbox_head, MultiBBoxHead)
+               and type(bbox_head).forward is MultiBBoxHead.forward
+               and all(f.dtype == torch.float32 and f.is_cuda for f in feats)
+               and all(p.dtype == torch.float32 for p in bbox_head._params()))
+    if fusable:
+        rois = rois.float().contiguous()
+        lh_rois, lw_rois, (lv_ori, lv_w, lv_h) = Fn.rff_roi_sets_op(rois, len(feats), bbox_roi_extractor.finest_scale)
+        layer = bbox_roi_extractor.roi_layers[0]
+        cls_score, bbox_pred, bbox_feats = Fn.rff_extract_head(
+            feats, [rois, lw_rois, lh_rois], [lv_ori, lv_w, lv_h], bbox_head._params(),
+            bbox_roi_extractor.featmap_strides[:len(feats)], layer.out_size[0], layer.sample_num)
+    else:
+        packed = bbox_head.prepack()      # weight re-layout on the side stream, beside the RoIAlign kernel
+        # get_adaptive_scale_rois + torch.cat([ori, lw, lh], dim=1) of the reference, produced in place by the fused extractor
+        bbox_feats = bbox_roi_extractor.extract_ar_sets(feats, rois)
+        cls_score, bbox_pred = bbox_head(bbox_feats, packed)
+    return dict(cls_score=cls_score, bbox_pred=bbox_pred, bbox_feats=bbox_feats)
 
 
 @HEADS.register_module()
@@ -203,12 +233,7 @@ class StandardRoIHead(nn.Module):
         self.bbox_head.init_weights()
 
     def _bbox_forward(self, x, rois):
-        n = self.bbox_roi_extractor.num_inputs
-        packed = self.bbox_head.prepack()      # weight re-layout on the side stream, beside the RoIAlign kernel
-        # get_adaptive_scale_rois + torch.cat([ori, lw, lh], dim=1) of the reference, produced in place by the fused extractor
-        bbox_feats = self.bbox_roi_extractor.extract_ar_sets(x[:n], rois)
-        cls_score, bbox_pred = self.bbox_head(bbox_feats, packed)
-        return dict(cls_score=cls_score, bbox_pred=bbox_pred, bbox_feats=bbox_feats)
+        return ar_rff_bbox_forward(self.bbox_roi_extractor, self.bbox_head, x, rois)
 
     def forward_dummy(self, x, proposals):
         from .bbox import bbox2roi
@@ -260,10 +285,7 @@ class CascadeRoIHead(nn.Module):
     def _bbox_forward(self, stage, x, rois):
         bbox_roi_extractor = self.bbox_roi_extractor[stage]
         bbox_head = self.bbox_head[stage]
-        packed = bbox_head.prepack()
-        bbox_feats = bbox_roi_extractor.extract_ar_sets(x[:bbox_roi_extractor.num_inputs], rois)
-        cls_score, bbox_pred = bbox_head(bbox_feats, packed)
-        return dict(cls_score=cls_score, bbox_pred=bbox_pred, bbox_feats=bbox_feats)
+        return ar_rff_bbox_forward(bbox_roi_extractor, bbox_head, x, rois)
 
     def forward_dummy(self, x, proposals):
         """bbox part of cascade_roi_head.py:101-112: every stage on the same proposals."""

@@ -170,11 +170,13 @@ int32_t arfe_roialign_bwd_prepared(const arfe_pyramid_t* pyr, float* const* dfea
 /* 3x3 conv, padding 1, on RoI features [R, C, 7, 7] (MultiBBoxHead wh_conv/hh_conv/final_conv,
  * bbox_heads/multirois_bbox_head.py:50-78,172-173,183) as an implicit GEMM on the matrix cores.
  * Weights w [C,C,3,3] are re-laid once per optimizer step into `packed` (arfe_conv3x3_packed_bytes(C) bytes:
- * [tap][co][ci] for the forward pass, [tap][ci][co] flipped for the data gradient).
+ * [tap][co][ci] for the forward pass, [tap][ci][co] flipped for the data gradient; each as pre-split (bf16 hi, lo) words
+ * for the generic kernels and as two bf16 planes for the LDS-DMA staging of the stage-once kernels).
  * x / y / dy / dx are addressed as base + r*roi_stride + c*49 + p, so a channel slice of the [R,3C,7,7]
  * concat is passed without a copy. */
 int64_t arfe_conv3x3_packed_bytes(int32_t C);
-int64_t arfe_conv3x3_workspace_bytes(int32_t C);   /* scratch of arfe_conv3x3_bwd_weight */
+int64_t arfe_conv3x3_workspace_bytes(int32_t C);   /* scratch of arfe_conv3x3_bwd_weight: 9 C C floats, or the per-slice
+                                                     * partial-sum slabs of the stage-once kernel (75.5 MB, C % 128 == 0) */
 int32_t arfe_conv3x3_pack_weights(int32_t C, const float* w, void* packed, void* stream);
 /* y = act(conv(x; w) + b) */
 int32_t arfe_conv3x3_fwd(int32_t R, int32_t C, const float* x, int64_t x_roi_stride, const void* packed,
