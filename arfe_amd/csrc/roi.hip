@@ -452,6 +452,8 @@ __global__ __launch_bounds__(256) void roialign_fwd_sep_kernel(RoiLevels L, RoiS
 constexpr int RB_NB = 4;
 constexpr int RB_SEGS = 4;        // slices of a long RoI list
 constexpr int RB_SEG_MIN = 32;    // lists up to this length stay in one workgroup (plain stores)
+constexpr int RB_GS = 60, RB_TS = 20;
+__device__ __forceinline__ int rb_wrow(int r) { return r * 8 + ((r >> 3) << 2); }   // start of weight row r (see the LDS note)
 // Only the tiles whose RoI list is cut into slices are summed with atomics and need a zeroed output: every other tile
 // (the empty ones included) is stored exactly once by the tile kernel.  Zeroing just those replaces a fill of the whole
 // pyramid gradient (183 MB per launch at the bench size).
@@ -482,9 +484,13 @@ __global__ __launch_bounds__(256) void roialign_bwd_tiles_kernel(RoiLevels L, Ro
                                                                  const int* __restrict__ offsets, const int* __restrict__ list,
                                                                  const int* __restrict__ lmeta,
                                                                  const float* __restrict__ wtab, int ntiles, int nchunks) {
-    __shared__ __attribute__((aligned(16))) float G_s[RB_NB][RB_CC][7][8];       // [roi][c][ph][pw (+1 pad)]
-    __shared__ float T_s[RB_CC][8][RT];                                          // [c][ph (row 7 = 0)][x], one RoI at a time
-    __shared__ __attribute__((aligned(16))) float wy_s[RB_NB][RT][8], wx_s[RB_NB][RT][8];
+    // LDS strides are chosen for the MFMA fragment accesses (64 banks x 4 B; PMC on the unpadded arrays: 56 % of the LDS
+    // cycles were bank conflicts): a channel of G takes 60 floats (the two channels of an A fragment then sit 60, not 56,
+    // floats apart), a T row 20 floats (the four 16-lane groups of a result store land 80 / 160 floats apart),
+    // weight rows 8..15 are shifted by 4 floats against rows 0..7.
+    __shared__ __attribute__((aligned(16))) float G_s[RB_NB][RB_CC][RB_GS];      // [roi][c][ph*8 + pw], pw = 7 zero pad
+    __shared__ float T_s[RB_CC][8][RB_TS];                                       // [c][ph (row 7 = 0)][x], one RoI at a time
+    __shared__ __attribute__((aligned(16))) float wy_s[RB_NB][RT * 8 + 4], wx_s[RB_NB][RT * 8 + 4];
     // coarse levels hold few tiles with long RoI lists: dispatch them first (reverse tile order) and cut a long
     // list into RB_SEGS slices handled by different workgroups (those add atomically into the zeroed output)
     // The channel chunk is the fast index of blockIdx.x: workgroups go round-robin to the 8 XCDs, so (16 chunks) an XCD
@@ -515,8 +521,8 @@ __global__ __launch_bounds__(256) void roialign_bwd_tiles_kernel(RoiLevels L, Ro
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     // pad lanes of the k = 8 contractions (bin 7) are never written by the staging below: zero them once
-    for (int i = tid; i < RB_NB * RT; i += 256) { wy_s[i / RT][i % RT][7] = 0.f; wx_s[i / RT][i % RT][7] = 0.f; }
-    for (int i = tid; i < RB_NB * RB_CC * 7; i += 256) G_s[i / (RB_CC * 7)][(i / 7) % RB_CC][i % 7][7] = 0.f;
+    for (int i = tid; i < RB_NB * RT; i += 256) { wy_s[i / RT][rb_wrow(i % RT) + 7] = 0.f; wx_s[i / RT][rb_wrow(i % RT) + 7] = 0.f; }
+    for (int i = tid; i < RB_NB * RB_CC * 7; i += 256) G_s[i / (RB_CC * 7)][(i / 7) % RB_CC][(i % 7) * 8 + 7] = 0.f;
 
     const int per_seg = (lend - lbeg + nseg - 1) / nseg;
     const int beg = lbeg + seg * per_seg;
@@ -577,13 +583,13 @@ __global__ __launch_bounds__(256) void roialign_bwd_tiles_kernel(RoiLevels L, Ro
         // ---- A/B: registers -> LDS ----
 #pragma unroll
         for (int j = 0; j < RB_NB; ++j) {
-            if (a_role) { if (a_axis) wx_s[j][a_r][a_pb] = pw[j]; else wy_s[j][a_r][a_pb] = pw[j]; }
+            if (a_role) { if (a_axis) wx_s[j][rb_wrow(a_r) + a_pb] = pw[j]; else wy_s[j][rb_wrow(a_r) + a_pb] = pw[j]; }
 #pragma unroll
             for (int i = 0; i < RB_GPT; ++i) {
                 const int q = tid + 256 * i;
                 if (q < RB_CC * 49) {
                     const int c = q / 49, r2 = q - c * 49, ph = r2 / 7;
-                    G_s[j][c][ph][r2 - ph * 7] = pg[j][i];
+                    G_s[j][c][ph * 8 + r2 - ph * 7] = pg[j][i];
                 }
             }
         }
@@ -597,16 +603,16 @@ __global__ __launch_bounds__(256) void roialign_bwd_tiles_kernel(RoiLevels L, Ro
                 f32x4_t t = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
-                    const float a = ph < 7 ? G_s[j][cl][ph < 7 ? ph : 6][4 * kk + lq] : 0.f;
-                    const float b = wx_s[j][l15][4 * kk + lq];
+                    const float a = ph < 7 ? G_s[j][cl][(ph < 7 ? ph : 6) * 8 + 4 * kk + lq] : 0.f;
+                    const float b = wx_s[j][rb_wrow(l15) + 4 * kk + lq];
                     t = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, t, 0, 0, 0);
                 }
                 // rows 4*lq + r of the M tile = (channel 4v + 2pr + (lq >> 1), bin 4*(lq & 1) + r), column l15
                 float* dst = &T_s[wv * 4 + pr * 2 + (lq >> 1)][4 * (lq & 1)][l15];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dst[r * RT] = t[r];
+                for (int r = 0; r < 4; ++r) dst[r * RB_TS] = t[r];
             }
-            const float a0 = wy_s[j][l15][lq], a1 = wy_s[j][l15][4 + lq];
+            const float a0 = wy_s[j][rb_wrow(l15) + lq], a1 = wy_s[j][rb_wrow(l15) + 4 + lq];
             __builtin_amdgcn_s_waitcnt(0xc07f);     // lgkmcnt(0): this wave's T rows have landed
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
