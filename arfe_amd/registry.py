@@ -81,6 +81,13 @@ SHARED_HEADS = Registry('shared_head')
 HEADS = Registry('head')
 LOSSES = Registry('loss')
 DETECTORS = Registry('detector')
+# the harness around the hot path: reference mmdet/core/anchor/builder.py:3, core/bbox/builder.py:3-5,
+# core/bbox/iou_calculators/builder.py:3
+ANCHOR_GENERATORS = Registry('Anchor generator')
+BBOX_ASSIGNERS = Registry('bbox_assigner')
+BBOX_SAMPLERS = Registry('bbox_sampler')
+BBOX_CODERS = Registry('bbox_coder')
+IOU_CALCULATORS = Registry('IoU calculator')
 
 
 def build(cfg, registry, default_args=None):
@@ -99,3 +106,36 @@ def build_roi_extractor(cfg):
 
 def build_head(cfg):
     return build(cfg, HEADS)
+
+
+def build_backbone(cfg):
+    return build(cfg, BACKBONES)
+
+
+def build_loss(cfg):
+    return build(cfg, LOSSES)
+
+
+def build_detector(cfg, train_cfg=None, test_cfg=None):
+    """mmdet/models/builder.py:46-48."""
+    return build(cfg, DETECTORS, dict(train_cfg=train_cfg, test_cfg=test_cfg))
+
+
+def build_anchor_generator(cfg, default_args=None):
+    return build_from_cfg(cfg, ANCHOR_GENERATORS, default_args)
+
+
+def build_assigner(cfg, **default_args):
+    return build_from_cfg(cfg, BBOX_ASSIGNERS, default_args)
+
+
+def build_sampler(cfg, **default_args):
+    return build_from_cfg(cfg, BBOX_SAMPLERS, default_args)
+
+
+def build_bbox_coder(cfg, **default_args):
+    return build_from_cfg(cfg, BBOX_CODERS, default_args)
+
+
+def build_iou_calculator(cfg, default_args=None):
+    return build_from_cfg(cfg, IOU_CALCULATORS, default_args)

@@ -9,7 +9,8 @@ from torch.nn.modules.utils import _pair
 from . import functional as Fn
 from .cnn import ConvModule, xavier_init
 from .fp16 import force_fp32
-from .registry import HEADS, ROI_EXTRACTORS, build_head, build_roi_extractor
+from .registry import (HEADS, ROI_EXTRACTORS, build_assigner, build_bbox_coder, build_head, build_loss,
+                       build_roi_extractor, build_sampler)
 from .roi_align import RoIAlign
 
 
@@ -97,6 +98,12 @@ class BBoxHead(nn.Module):
         self.reg_decoded_bbox = reg_decoded_bbox
         self.fp16_enabled = False
         self.bbox_coder_cfg, self.loss_cls_cfg, self.loss_bbox_cfg = bbox_coder, loss_cls, loss_bbox
+        # training side (the harness): built only when the config names them, as the hot-path users
+        # construct the head without coder / losses
+        from . import detector  # noqa: F401  (registers the coder / loss classes)
+        self.bbox_coder = build_bbox_coder(bbox_coder) if bbox_coder is not None else None
+        self.loss_cls = build_loss(loss_cls) if loss_cls is not None else None
+        self.loss_bbox = build_loss(loss_bbox) if loss_bbox is not None else None
         in_ch = in_channels * self.roi_feat_area
         self.fc_cls = nn.Linear(in_ch, num_classes + 1)
         self.fc_reg = nn.Linear(in_ch, 4 if reg_class_agnostic else 4 * num_classes)
@@ -106,6 +113,84 @@ class BBoxHead(nn.Module):
         nn.init.constant_(self.fc_cls.bias, 0)
         nn.init.normal_(self.fc_reg.weight, 0, 0.001)
         nn.init.constant_(self.fc_reg.bias, 0)
+
+    # ---- training targets / losses / box refinement (bbox_head.py:86-156, :158-205, :262-352): plain PyTorch host logic ----
+    def _get_target_single(self, pos_bboxes, neg_bboxes, pos_gt_bboxes, pos_gt_labels, cfg):
+        """positives first, then negatives: labels (background = num_classes), label weights, encoded box targets."""
+        num_pos, num_neg = pos_bboxes.size(0), neg_bboxes.size(0)
+        n = num_pos + num_neg
+        labels = pos_bboxes.new_full((n, ), self.num_classes, dtype=torch.long)
+        label_weights = pos_bboxes.new_zeros(n)
+        bbox_targets, bbox_weights = pos_bboxes.new_zeros(n, 4), pos_bboxes.new_zeros(n, 4)
+        if num_pos > 0:
+            labels[:num_pos] = pos_gt_labels
+            pw = cfg['pos_weight'] if isinstance(cfg, dict) else cfg.pos_weight
+            label_weights[:num_pos] = 1.0 if pw <= 0 else pw
+            bbox_targets[:num_pos, :] = (pos_gt_bboxes if self.reg_decoded_bbox else
+                                         self.bbox_coder.encode(pos_bboxes, pos_gt_bboxes))
+            bbox_weights[:num_pos, :] = 1.0
+        if num_neg > 0:
+            label_weights[-num_neg:] = 1.0
+        return labels, label_weights, bbox_targets, bbox_weights
+
+    def get_targets(self, sampling_results, gt_bboxes, gt_labels, rcnn_train_cfg, concat=True):
+        per_img = [self._get_target_single(r.pos_bboxes, r.neg_bboxes, r.pos_gt_bboxes, r.pos_gt_labels, rcnn_train_cfg)
+                   for r in sampling_results]
+        cols = tuple([p[j] for p in per_img] for j in range(4))
+        return tuple(torch.cat(c, 0) for c in cols) if concat else cols
+
+    def loss(self, cls_score, bbox_pred, rois, labels, label_weights, bbox_targets, bbox_weights, reduction_override=None):
+        from .detector.losses import accuracy
+        losses = dict()
+        if cls_score is not None:
+            cls_score = cls_score.float()                         # @force_fp32(apply_to=('cls_score', 'bbox_pred'))
+            avg_factor = max(torch.sum(label_weights > 0).float().item(), 1.)
+            if cls_score.numel() > 0:
+                losses['loss_cls'] = self.loss_cls(cls_score, labels, label_weights, avg_factor=avg_factor,
+                                                   reduction_override=reduction_override)
+                losses['acc'] = accuracy(cls_score, labels)
+        if bbox_pred is not None:
+            bbox_pred = bbox_pred.float()
+            pos = (labels >= 0) & (labels < self.num_classes)
+            if pos.any():
+                if self.reg_decoded_bbox:
+                    bbox_pred = self.bbox_coder.decode(rois[:, 1:], bbox_pred)
+                if self.reg_class_agnostic:
+                    pos_pred = bbox_pred.view(bbox_pred.size(0), 4)[pos]
+                else:
+                    pos_pred = bbox_pred.view(bbox_pred.size(0), -1, 4)[pos, labels[pos]]
+                losses['loss_bbox'] = self.loss_bbox(pos_pred, bbox_targets[pos], bbox_weights[pos],
+                                                     avg_factor=bbox_targets.size(0), reduction_override=reduction_override)
+            else:
+                losses['loss_bbox'] = bbox_pred.sum() * 0
+        return losses
+
+    def regress_by_class(self, rois, label, bbox_pred, img_meta):
+        """the box of the given class applied to each roi ([n, 4] or [n, 5] with the batch column kept); Cascade R-CNN."""
+        assert rois.size(1) in (4, 5), repr(rois.shape)
+        bbox_pred = bbox_pred.float()
+        if not self.reg_class_agnostic:
+            idx = label * 4
+            bbox_pred = torch.gather(bbox_pred, 1, torch.stack((idx, idx + 1, idx + 2, idx + 3), 1))
+        assert bbox_pred.size(1) == 4
+        if rois.size(1) == 4:
+            return self.bbox_coder.decode(rois, bbox_pred, max_shape=img_meta['img_shape'])
+        boxes = self.bbox_coder.decode(rois[:, 1:], bbox_pred, max_shape=img_meta['img_shape'])
+        return torch.cat((rois[:, [0]], boxes), dim=1)
+
+    def refine_bboxes(self, rois, labels, bbox_preds, pos_is_gts, img_metas):
+        """per image: regress every roi by its (target) class, drop the rois that were ground-truth boxes (they lead the
+        positives of each image) -> the next cascade stage's proposals."""
+        img_ids = rois[:, 0].long().unique(sorted=True)
+        assert img_ids.numel() <= len(img_metas)
+        out = []
+        for i in range(len(img_metas)):
+            inds = torch.nonzero(rois[:, 0] == i, as_tuple=False).squeeze(dim=1)
+            boxes = self.regress_by_class(rois[inds, 1:], labels[inds], bbox_preds[inds], img_metas[i])
+            keep = pos_is_gts[i].new_ones(inds.numel())
+            keep[:len(pos_is_gts[i])] = 1 - pos_is_gts[i]
+            out.append(boxes[keep.type(torch.bool)])
+        return out
 
 
 @HEADS.register_module()
@@ -223,10 +308,19 @@ class StandardRoIHead(nn.Module):
         self.train_cfg, self.test_cfg = train_cfg, test_cfg
         self.bbox_roi_extractor = build_roi_extractor(bbox_roi_extractor)
         self.bbox_head = build_head(bbox_head)
+        self.init_assigner_sampler()
 
     @property
     def with_bbox(self):
         return True
+
+    def init_assigner_sampler(self):
+        """standard_roi_head.py:22-29."""
+        self.bbox_assigner = self.bbox_sampler = None
+        if self.train_cfg:
+            from . import detector  # noqa: F401  (registers assigner / sampler classes)
+            self.bbox_assigner = build_assigner(self.train_cfg['assigner'])
+            self.bbox_sampler = build_sampler(self.train_cfg['sampler'])
 
     def init_weights(self, pretrained=None):
         self.bbox_roi_extractor.init_weights()
@@ -240,8 +334,31 @@ class StandardRoIHead(nn.Module):
         r = self._bbox_forward(x, bbox2roi([proposals]))
         return (r['cls_score'], r['bbox_pred'])
 
-    def forward_train(self, *a, **k):
-        raise NotImplementedError("target assignment / losses are outside the AR-FPN + AR-RFF hot path")
+    def forward_train(self, x, img_metas, proposal_list, gt_bboxes, gt_labels, gt_bboxes_ignore=None, gt_masks=None):
+        """standard_roi_head.py:64-133 (bbox branch): assign + sample per image, the AR-RFF body on the sampled RoIs,
+        targets and losses.  Host logic around the hot path."""
+        if self.bbox_assigner is None:
+            raise RuntimeError("StandardRoIHead.forward_train needs train_cfg (assigner / sampler)")
+        num_imgs = len(img_metas)
+        ignore = gt_bboxes_ignore if gt_bboxes_ignore is not None else [None] * num_imgs
+        sampling_results = []
+        for i in range(num_imgs):
+            assign_result = self.bbox_assigner.assign(proposal_list[i], gt_bboxes[i], ignore[i], gt_labels[i])
+            sampling_results.append(self.bbox_sampler.sample(assign_result, proposal_list[i], gt_bboxes[i], gt_labels[i]))
+        losses = dict()
+        losses.update(self._bbox_forward_train(x, sampling_results, gt_bboxes, gt_labels, img_metas)['loss_bbox'])
+        return losses
+
+    def _bbox_forward_train(self, x, sampling_results, gt_bboxes, gt_labels, img_metas):
+        """standard_roi_head.py:172-190 with the two-value head of the AR path (HEAD passes a third `multi_cls` output of
+        an ablation head through)."""
+        from .bbox import bbox2roi
+        rois = bbox2roi([res.bboxes for res in sampling_results])
+        bbox_results = self._bbox_forward(x, rois)
+        bbox_targets = self.bbox_head.get_targets(sampling_results, gt_bboxes, gt_labels, self.train_cfg)
+        bbox_results.update(loss_bbox=self.bbox_head.loss(bbox_results['cls_score'], bbox_results['bbox_pred'], rois,
+                                                          *bbox_targets))
+        return bbox_results
 
 
 @HEADS.register_module()
@@ -263,6 +380,16 @@ class CascadeRoIHead(nn.Module):
         self.stage_loss_weights = stage_loss_weights
         self.train_cfg, self.test_cfg = train_cfg, test_cfg
         self.init_bbox_head(bbox_roi_extractor, bbox_head)
+        self.init_assigner_sampler()
+
+    def init_assigner_sampler(self):
+        """one assigner / sampler per stage (cascade_roi_head.py:83-91)."""
+        self.bbox_assigner, self.bbox_sampler = [], []
+        if self.train_cfg is not None:
+            from . import detector  # noqa: F401
+            for cfg in self.train_cfg:
+                self.bbox_assigner.append(build_assigner(cfg['assigner']))
+                self.bbox_sampler.append(build_sampler(cfg['sampler']))
 
     def init_bbox_head(self, bbox_roi_extractor, bbox_head):
         """One extractor and one head per stage; a single config dict stands for every stage."""
@@ -297,5 +424,37 @@ class CascadeRoIHead(nn.Module):
             outs = outs + (r['cls_score'], r['bbox_pred'])
         return outs
 
-    def forward_train(self, *a, **k):
-        raise NotImplementedError("target assignment / box refinement / losses are outside the AR-FPN + AR-RFF hot path")
+    def _bbox_forward_train(self, stage, x, sampling_results, gt_bboxes, gt_labels, rcnn_train_cfg):
+        """cascade_roi_head.py:151-166."""
+        from .bbox import bbox2roi
+        rois = bbox2roi([res.bboxes for res in sampling_results])
+        bbox_results = self._bbox_forward(stage, x, rois)
+        bbox_targets = self.bbox_head[stage].get_targets(sampling_results, gt_bboxes, gt_labels, rcnn_train_cfg)
+        loss_bbox = self.bbox_head[stage].loss(bbox_results['cls_score'], bbox_results['bbox_pred'], rois, *bbox_targets)
+        bbox_results.update(loss_bbox=loss_bbox, rois=rois, bbox_targets=bbox_targets)
+        return bbox_results
+
+    def forward_train(self, x, img_metas, proposal_list, gt_bboxes, gt_labels, gt_bboxes_ignore=None, gt_masks=None):
+        """cascade_roi_head.py:192-283 (bbox branch): every stage assigns / samples the current proposals, runs the AR-RFF
+        body, weighs its losses by stage_loss_weights and (but for the last) refines the boxes for the next stage."""
+        if not self.bbox_assigner:
+            raise RuntimeError("CascadeRoIHead.forward_train needs train_cfg (one assigner / sampler per stage)")
+        losses = dict()
+        num_imgs = len(img_metas)
+        ignore = gt_bboxes_ignore if gt_bboxes_ignore is not None else [None] * num_imgs
+        for i in range(self.num_stages):
+            self.current_stage = i
+            lw = self.stage_loss_weights[i]
+            sampling_results = []
+            for j in range(num_imgs):
+                assign_result = self.bbox_assigner[i].assign(proposal_list[j], gt_bboxes[j], ignore[j], gt_labels[j])
+                sampling_results.append(self.bbox_sampler[i].sample(assign_result, proposal_list[j], gt_bboxes[j], gt_labels[j]))
+            bbox_results = self._bbox_forward_train(i, x, sampling_results, gt_bboxes, gt_labels, self.train_cfg[i])
+            for name, value in bbox_results['loss_bbox'].items():
+                losses[f's{i}.{name}'] = value * lw if 'loss' in name else value
+            if i < self.num_stages - 1:
+                pos_is_gts = [res.pos_is_gt for res in sampling_results]
+                with torch.no_grad():
+                    proposal_list = self.bbox_head[i].refine_bboxes(bbox_results['rois'], bbox_results['bbox_targets'][0],
+                                                                    bbox_results['bbox_pred'], pos_is_gts, img_metas)
+        return losses

@@ -343,6 +343,80 @@ def main():
     e2e_case(ns)
     fpn_cases(ns)
     fp16_case(ns)
+    harness_case()
+
+
+def _boxes(n, w, h, gen, lo=4.0, hi=120.0):
+    wh = torch.exp(torch.rand(n, 2, generator=gen) * (np.log(hi) - np.log(lo)) + np.log(lo))
+    xy = torch.rand(n, 2, generator=gen) * (torch.tensor([w, h], dtype=torch.float32) - wh).clamp(min=1.0)
+    return torch.cat([xy, xy + wh], 1)
+
+
+def harness_case():
+    """Fixtures of the detector harness from the reference's own box / anchor / loss code."""
+    from oracle.ref_loader import load_reference_harness
+    hs = load_reference_harness()
+    g = torch.Generator().manual_seed(21)
+    d = {}
+    # anchors: the RPN generator of the AR configs on a 60 x 90 image padded to 64 x 96
+    gen = hs.AnchorGenerator(strides=[4, 8, 16, 32, 64], ratios=[0.5, 1.0, 2.0], scales=[8])
+    sizes = [(16, 24), (8, 12), (4, 6), (2, 3), (1, 2)]
+    d['anchor_sizes'] = torch.tensor(sizes)
+    anchors = gen.grid_anchors(sizes, device='cpu')
+    flags = gen.valid_flags(sizes, (60, 90, 3), device='cpu')
+    d['anchors'] = torch.cat(anchors)
+    d['anchor_valid'] = torch.cat(flags)
+    d['anchor_inside'] = hs.anchor_inside_flags(torch.cat(anchors), torch.cat(flags), (60, 90), allowed_border=0)
+    gen2 = hs.AnchorGenerator(strides=[8, 16], ratios=[1.0], octave_base_scale=4, scales_per_octave=3, scale_major=False)
+    d['anchors_octave'] = torch.cat(gen2.grid_anchors([(3, 4), (2, 2)], device='cpu'))
+    # coder
+    props, gts = _boxes(300, 96, 64, g), _boxes(300, 96, 64, g)
+    d['coder_props'], d['coder_gts'] = props, gts
+    means, stds = (0., 0., 0., 0.), (0.1, 0.1, 0.2, 0.2)
+    d['deltas'] = hs.bbox2delta(props, gts, means, stds)
+    raw = torch.randn(300, 12, generator=g) * 0.7
+    d['raw_deltas'] = raw
+    d['decoded'] = hs.delta2bbox(props, raw, means, stds, max_shape=(64, 96))
+    d['decoded_noclip'] = hs.delta2bbox(props, raw[:, :4] * 8.0, (0.1, 0., 0., 0.), (1., 1., 1., 1.))
+    # overlaps
+    b1, b2 = _boxes(40, 96, 64, g), _boxes(25, 96, 64, g)
+    d['ov_b1'], d['ov_b2'] = b1, b2
+    d['iou'] = hs.bbox_overlaps(b1, b2)
+    d['iof'] = hs.bbox_overlaps(b1, b2, mode='iof')
+    d['iou_aligned'] = hs.bbox_overlaps(b1[:25], b2, is_aligned=True)
+    # assigner: the RPN and the R-CNN settings of the AR configs (+ duplicates of gt boxes among the candidates: ties)
+    cand = torch.cat([_boxes(500, 96, 64, g), b2[:5], b2[:5] + 0.5])
+    labels = torch.randint(0, 80, (25, ), generator=g)
+    d['as_boxes'], d['as_gts'], d['as_labels'] = cand, b2, labels
+    rpn = hs.MaxIoUAssigner(pos_iou_thr=0.7, neg_iou_thr=0.3, min_pos_iou=0.3, match_low_quality=True, ignore_iof_thr=-1)
+    r = rpn.assign(cand, b2, None, None)
+    d['as_rpn_inds'], d['as_rpn_max'] = r.gt_inds, r.max_overlaps
+    rcnn = hs.MaxIoUAssigner(pos_iou_thr=0.5, neg_iou_thr=0.5, min_pos_iou=0.5, match_low_quality=False, ignore_iof_thr=-1)
+    r = rcnn.assign(cand, b2, None, labels)
+    d['as_rcnn_inds'], d['as_rcnn_labels'] = r.gt_inds, r.labels
+    one = hs.MaxIoUAssigner(pos_iou_thr=0.6, neg_iou_thr=(0.1, 0.4), min_pos_iou=0.2, gt_max_assign_all=False,
+                            ignore_iof_thr=0.5)
+    r = one.assign(cand, b2[:10], b2[10:14], labels[:10])
+    d['as_one_inds'], d['as_one_labels'] = r.gt_inds, r.labels
+    # losses: N = 200 >= 81 samples (the fork's softmax criterion indexes a length-N vector with class indices)
+    pred, lab = torch.randn(200, 81, generator=g), torch.randint(0, 81, (200, ), generator=g)
+    w = (torch.rand(200, generator=g) > 0.2).float()
+    d['ce_pred'], d['ce_label'], d['ce_weight'] = pred, lab, w
+    ce = hs.CrossEntropyLoss(use_sigmoid=False, loss_weight=1.0)
+    d['ce_plain'] = ce(pred, lab)
+    d['ce_weighted'] = ce(pred, lab, w, avg_factor=float(w.sum()))
+    d['ce_none'] = ce(pred, lab, w, reduction_override='none')
+    d['acc'] = hs.accuracy(pred, lab)
+    bp, bl = torch.randn(500, 1, generator=g), torch.randint(0, 2, (500, ), generator=g)
+    bw = (torch.rand(500, generator=g) > 0.3).float()
+    d['bce_pred'], d['bce_label'], d['bce_weight'] = bp, bl, bw
+    d['bce'] = hs.CrossEntropyLoss(use_sigmoid=True, loss_weight=1.0)(bp, bl, bw, avg_factor=256.0)
+    rp, rt, rw = torch.randn(64, 4, generator=g), torch.randn(64, 4, generator=g), (torch.rand(64, 4, generator=g) > 0.5).float()
+    d['reg_pred'], d['reg_target'], d['reg_weight'] = rp, rt, rw
+    d['l1'] = hs.L1Loss(loss_weight=1.0)(rp, rt, rw, avg_factor=512.0)
+    d['smooth_l1'] = hs.SmoothL1Loss(beta=1.0 / 9.0, loss_weight=1.0)(rp, rt, rw, avg_factor=512.0)
+    np.savez_compressed(os.path.join(OUT, 'harness.npz'), **npd(d))
+    print('harness.npz', {k: tuple(v.shape) for k, v in d.items() if hasattr(v, 'shape')})
 
 
 def fpn_cases(ns):
@@ -354,6 +428,9 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'fpn':     # only the base-FPN fixtures (keeps the others byte-identical)
         os.makedirs(OUT, exist_ok=True)
         fpn_cases(load_reference())
+    elif len(sys.argv) > 1 and sys.argv[1] == 'harness':  # only the detector-harness fixture
+        os.makedirs(OUT, exist_ok=True)
+        harness_case()
     elif len(sys.argv) > 1 and sys.argv[1] == 'fp16':  # only the fp16-mode fixture
         os.makedirs(OUT, exist_ok=True)
         fp16_case(load_reference())

@@ -202,6 +202,48 @@ def load_reference():
     return ns
 
 
+def load_reference_harness():
+    """The reference's box / anchor / loss helpers of the detector harness, loaded by path like the
+    hot-path files: core/bbox/{iou_calculators/iou2d_calculator, coder/delta_xywh_bbox_coder, assigners/max_iou_assigner},
+    core/anchor/{anchor_generator, utils}, models/losses/{utils, cross_entropy_loss, smooth_l1_loss, accuracy}.
+    Their `.builder` siblings (thin wrappers over the absent mmcv Registry) are stand-ins."""
+    assert reference_available(), f"{REF_ROOT} not present"
+    _install_stubs()
+    sys.modules['mmcv'].is_tuple_of = lambda seq, t: isinstance(seq, tuple) and all(isinstance(s, t) for s in seq)
+    regs = {n: _Registry(n) for n in ('IOU_CALCULATORS', 'BBOX_CODERS', 'BBOX_ASSIGNERS', 'BBOX_SAMPLERS', 'ANCHOR_GENERATORS')}
+    _mod('mmdet.utils')
+    um = _load('mmdet.utils.util_mixins', 'mmdet/utils/util_mixins.py')
+    sys.modules['mmdet.utils'].util_mixins = um
+    _mod('mmdet.core.bbox')
+    _mod('mmdet.core.bbox.builder', BBOX_CODERS=regs['BBOX_CODERS'], BBOX_ASSIGNERS=regs['BBOX_ASSIGNERS'],
+         BBOX_SAMPLERS=regs['BBOX_SAMPLERS'])
+    ic = _mod('mmdet.core.bbox.iou_calculators')
+    _mod('mmdet.core.bbox.iou_calculators.builder', IOU_CALCULATORS=regs['IOU_CALCULATORS'],
+         build_iou_calculator=lambda cfg, default_args=None: _build_from_cfg(cfg, regs['IOU_CALCULATORS'], default_args))
+    iou = _load('mmdet.core.bbox.iou_calculators.iou2d_calculator', 'mmdet/core/bbox/iou_calculators/iou2d_calculator.py')
+    ic.build_iou_calculator = sys.modules['mmdet.core.bbox.iou_calculators.builder'].build_iou_calculator
+    _mod('mmdet.core.bbox.coder')
+    _load('mmdet.core.bbox.coder.base_bbox_coder', 'mmdet/core/bbox/coder/base_bbox_coder.py')
+    coder = _load('mmdet.core.bbox.coder.delta_xywh_bbox_coder', 'mmdet/core/bbox/coder/delta_xywh_bbox_coder.py')
+    _mod('mmdet.core.bbox.assigners')
+    _load('mmdet.core.bbox.assigners.assign_result', 'mmdet/core/bbox/assigners/assign_result.py')
+    _load('mmdet.core.bbox.assigners.base_assigner', 'mmdet/core/bbox/assigners/base_assigner.py')
+    asg = _load('mmdet.core.bbox.assigners.max_iou_assigner', 'mmdet/core/bbox/assigners/max_iou_assigner.py')
+    _mod('mmdet.core.anchor')
+    _mod('mmdet.core.anchor.builder', ANCHOR_GENERATORS=regs['ANCHOR_GENERATORS'])
+    anc = _load('mmdet.core.anchor.anchor_generator', 'mmdet/core/anchor/anchor_generator.py')
+    autil = _load('mmdet.core.anchor.utils', 'mmdet/core/anchor/utils.py')
+    _load('mmdet.models.losses.utils', 'mmdet/models/losses/utils.py')
+    ce = _load('mmdet.models.losses.cross_entropy_loss', 'mmdet/models/losses/cross_entropy_loss.py')
+    l1 = _load('mmdet.models.losses.smooth_l1_loss', 'mmdet/models/losses/smooth_l1_loss.py')
+    acc = _load('mmdet.models.losses.accuracy', 'mmdet/models/losses/accuracy.py')
+    return types.SimpleNamespace(
+        bbox_overlaps=iou.bbox_overlaps, bbox2delta=coder.bbox2delta, delta2bbox=coder.delta2bbox,
+        DeltaXYWHBBoxCoder=coder.DeltaXYWHBBoxCoder, MaxIoUAssigner=asg.MaxIoUAssigner,
+        AnchorGenerator=anc.AnchorGenerator, anchor_inside_flags=autil.anchor_inside_flags,
+        CrossEntropyLoss=ce.CrossEntropyLoss, L1Loss=l1.L1Loss, SmoothL1Loss=l1.SmoothL1Loss, accuracy=acc.accuracy)
+
+
 def load_reference_roi_align():
     """The compiled reference RoIAlign (oracle/_ref, built by oracle/build_ref.py)."""
     here = os.path.dirname(os.path.abspath(__file__))

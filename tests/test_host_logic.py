@@ -230,5 +230,5 @@ def test_cascade_roi_head_builds_per_stage_modules():
     with pytest.raises(AssertionError):
         arfe_amd.build_head(dict(type='CascadeRoIHead', num_stages=2, stage_loss_weights=[1, 1], bbox_roi_extractor=ext,
                                  bbox_head=[dict(head)]))
-    with pytest.raises(NotImplementedError):
-        rh.forward_train()
+    with pytest.raises(RuntimeError, match='train_cfg'):      # built without train_cfg: no assigners / samplers
+        rh.forward_train([], [], [], [], [])
