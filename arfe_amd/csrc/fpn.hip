@@ -459,6 +459,199 @@ __global__ __launch_bounds__(256) void fpn_scatter_bwd_dbsf_kernel(Levels lv, Le
 }
 
 // =========================================================================================================
+// backward A+B fused (round 2): ONE pass over the upstream gradient g produces both
+//     dm_i[dst]  = sum_c g_i[c][dst] * bsf[c][src(dst)]        (every dst pixel has exactly one nearest source)
+//     dbsf[c][s] = sum_i sum_{dst: src(dst) = s} g_i[c][dst] * (a_i + b_i)[dst]
+// instead of reading g twice (maps kernel + dbsf kernel: 2 x 183 MB at the bench size).  A thread owns one refine-level
+// pixel s of one image and walks a range of channels; the destination windows of s (NF finer levels with windows of
+// (2^sh)^2 pixels, the refine level itself, at most one pixel on every coarser level) and their gate sums live in
+// registers, so per channel it reads the windows once (16 / 8 / 4-byte reads, lanes along sx: contiguous rows), adds
+// g*bsf[c][s] into its dm registers and the gate-weighted sum into dbsf[c][s].  The 4 waves of a workgroup take the 4
+// quarters of a channel chunk for the SAME 64 source pixels; dm is reduced across them through LDS and added atomically
+// into the zeroed dpa maps (one add per chunk), which fpn_scatter_bwd_maps_finish_kernel turns into dpre_a / dpre_b.
+// Instantiated for NF = 0, 1, 2 finer levels whose size ratio to the refine level is exactly 2^(r - i); other pyramids
+// (ragged sizes, refine level 3 or 4) keep the two-kernel form.
+// =========================================================================================================
+template <int NF>
+__global__ __launch_bounds__(256) void fpn_scatter_bwd_fused_kernel(Levels lv, LevelPtrs gout, const float* __restrict__ bsf,
+                                                                    LevelPtrs a, LevelPtrs b, LevelMutPtrs dpa,
+                                                                    float* __restrict__ dbsf) {
+    constexpr int W0 = NF >= 1 ? (1 << NF) : 1;              // window edge of level 0 (finest)
+    constexpr int W1 = NF >= 2 ? (1 << (NF - 1)) : 1;        // window edge of level 1 when NF == 2
+    constexpr int NC = ARFE_MAX_LEVELS;                       // slots for the refine level and the coarser ones
+    __shared__ float red[3][64][W0 * W0 + W1 * W1 + NC];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hr = lv.H[lv.r], wr = lv.W[lv.r], npx = hr * wr;
+    const int blocks_per_img = (npx + 63) / 64;
+    const int bi = blockIdx.x / blocks_per_img;
+    int s = (blockIdx.x - bi * blocks_per_img) * 64 + lane;
+    const bool active = s < npx;
+    if (!active) s = npx - 1;
+    const int sy = s / wr, sx = s - sy * wr;
+    // channel range of this wave
+    const int cchunk = (lv.C + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int ch0 = blockIdx.y * cchunk, ch1 = ch0 + cchunk < lv.C ? ch0 + cchunk : lv.C;
+    const int cq = (ch1 - ch0 + 3) / 4;
+    const int c_begin = ch0 + wave * cq < ch1 ? ch0 + wave * cq : ch1;
+    const int c_end = c_begin + cq < ch1 ? c_begin + cq : ch1;
+
+    // ---- window geometry + gate sums (channel independent) ----
+    float s0[W0 * W0], s1[W1 * W1], sc[NC];
+    float d0[W0 * W0], d1[W1 * W1], dc[NC];
+    int64_t o0 = 0, o1 = 0, oc[NC];            // element offset of the window's first pixel inside a channel plane
+    bool vc[NC];
+#pragma unroll
+    for (int e = 0; e < W0 * W0; ++e) { s0[e] = 0.f; d0[e] = 0.f; }
+#pragma unroll
+    for (int e = 0; e < W1 * W1; ++e) { s1[e] = 0.f; d1[e] = 0.f; }
+    if constexpr (NF >= 1) {
+        const int w = lv.W[0];
+        o0 = (int64_t)(sy * W0) * w + sx * W0;
+        const float* ap = a.p[0] + (int64_t)bi * lv.H[0] * w + o0;
+        const float* bp = b.p[0] + (int64_t)bi * lv.H[0] * w + o0;
+#pragma unroll
+        for (int yy = 0; yy < W0; ++yy)
+#pragma unroll
+            for (int xx = 0; xx < W0; ++xx) s0[yy * W0 + xx] = ap[yy * w + xx] + bp[yy * w + xx];
+    }
+    if constexpr (NF >= 2) {
+        const int w = lv.W[1];
+        o1 = (int64_t)(sy * W1) * w + sx * W1;
+        const float* ap = a.p[1] + (int64_t)bi * lv.H[1] * w + o1;
+        const float* bp = b.p[1] + (int64_t)bi * lv.H[1] * w + o1;
+#pragma unroll
+        for (int yy = 0; yy < W1; ++yy)
+#pragma unroll
+            for (int xx = 0; xx < W1; ++xx) s1[yy * W1 + xx] = ap[yy * w + xx] + bp[yy * w + xx];
+    }
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        const int i = NF + k;                                  // refine level (k = 0) and the coarser ones
+        sc[k] = 0.f; dc[k] = 0.f; oc[k] = 0; vc[k] = false;
+        if (i >= lv.n) continue;
+        const int h = lv.H[i], w = lv.W[i];
+        int y0, y1, x0, x1;
+        const int sh = lv.sh[i];
+        if (sh == 0) { y0 = sy; y1 = sy + 1; x0 = sx; x1 = sx + 1; }
+        else if (sh != SH_GENERAL && sh < 0) {
+            const int f = -sh, m = (1 << f) - 1;
+            const bool hit = !(sy & m) && !(sx & m);
+            y0 = sy >> f; x0 = sx >> f; y1 = y0 + (hit ? 1 : 0); x1 = x0 + (hit ? 1 : 0);
+        } else {
+            const float ys = nearest_scale(hr, h), xs = nearest_scale(wr, w);
+            y0 = nearest_dst_begin(sy, hr, h, ys); y1 = nearest_dst_begin(sy + 1, hr, h, ys);
+            x0 = nearest_dst_begin(sx, wr, w, xs); x1 = nearest_dst_begin(sx + 1, wr, w, xs);
+        }
+        vc[k] = y1 > y0 && x1 > x0;       // (a coarser map has at most one pixel whose nearest source is s)
+        if (vc[k]) {
+            oc[k] = (int64_t)y0 * w + x0;
+            sc[k] = a.p[i][(int64_t)bi * h * w + oc[k]] + b.p[i][(int64_t)bi * h * w + oc[k]];
+        }
+    }
+    // ---- channel loop: two channels in flight ----
+    const int64_t plane_r = (int64_t)npx;
+    auto one = [&](int c, float (&g0)[W0 * W0], float (&g1)[W1 * W1], float (&gc)[NC], float& u) {
+        const int64_t bc = (int64_t)bi * lv.C + c;
+        u = bsf[bc * plane_r + s];
+        if constexpr (NF >= 1) {
+            const int w = lv.W[0];
+            const float* gp = gout.p[0] + bc * (int64_t)lv.H[0] * w + o0;
+#pragma unroll
+            for (int yy = 0; yy < W0; ++yy) {
+                if constexpr (W0 == 4) {
+                    const float4_u v = *reinterpret_cast<const float4_u*>(gp + yy * w);
+                    g0[yy * 4 + 0] = v[0]; g0[yy * 4 + 1] = v[1]; g0[yy * 4 + 2] = v[2]; g0[yy * 4 + 3] = v[3];
+                } else {
+#pragma unroll
+                    for (int xx = 0; xx < W0; ++xx) g0[yy * W0 + xx] = gp[yy * w + xx];
+                }
+            }
+        }
+        if constexpr (NF >= 2) {
+            const int w = lv.W[1];
+            const float* gp = gout.p[1] + bc * (int64_t)lv.H[1] * w + o1;
+#pragma unroll
+            for (int yy = 0; yy < W1; ++yy)
+#pragma unroll
+                for (int xx = 0; xx < W1; ++xx) g1[yy * W1 + xx] = gp[yy * w + xx];
+        }
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            const int i = NF + k;
+            gc[k] = 0.f;
+            if (i < lv.n && vc[k]) gc[k] = gout.p[i][bc * (int64_t)lv.H[i] * lv.W[i] + oc[k]];
+        }
+    };
+    auto fold = [&](int c, const float (&g0)[W0 * W0], const float (&g1)[W1 * W1], const float (&gc)[NC], float u) {
+        float acc = 0.f;
+        if constexpr (NF >= 1) {
+#pragma unroll
+            for (int e = 0; e < W0 * W0; ++e) { d0[e] += g0[e] * u; acc += g0[e] * s0[e]; }
+        }
+        if constexpr (NF >= 2) {
+#pragma unroll
+            for (int e = 0; e < W1 * W1; ++e) { d1[e] += g1[e] * u; acc += g1[e] * s1[e]; }
+        }
+#pragma unroll
+        for (int k = 0; k < NC; ++k) { dc[k] += gc[k] * u; acc += gc[k] * sc[k]; }
+        if (active) dbsf[((int64_t)bi * lv.C + c) * plane_r + s] = acc;
+    };
+    int c = c_begin;
+    for (; c + 1 < c_end; c += 2) {
+        float ga0[W0 * W0], ga1[W1 * W1], gac[NC], ua;
+        float gb0[W0 * W0], gb1[W1 * W1], gbc[NC], ub;
+        one(c, ga0, ga1, gac, ua);
+        one(c + 1, gb0, gb1, gbc, ub);
+        fold(c, ga0, ga1, gac, ua);
+        fold(c + 1, gb0, gb1, gbc, ub);
+    }
+    if (c < c_end) {
+        float ga0[W0 * W0], ga1[W1 * W1], gac[NC], ua;
+        one(c, ga0, ga1, gac, ua);
+        fold(c, ga0, ga1, gac, ua);
+    }
+    // ---- dm: reduce the four channel quarters, one atomic add per destination pixel and chunk ----
+    constexpr int ND = W0 * W0 + W1 * W1 + NC;
+    if (wave > 0) {
+        float* r = &red[wave - 1][lane][0];
+#pragma unroll
+        for (int e = 0; e < W0 * W0; ++e) r[e] = d0[e];
+#pragma unroll
+        for (int e = 0; e < W1 * W1; ++e) r[W0 * W0 + e] = d1[e];
+#pragma unroll
+        for (int k = 0; k < NC; ++k) r[W0 * W0 + W1 * W1 + k] = dc[k];
+    }
+    __syncthreads();
+    if (wave == 0 && active) {
+        auto total = [&](int e, float mine) { return ((mine + red[0][lane][e]) + red[1][lane][e]) + red[2][lane][e]; };
+        if constexpr (NF >= 1) {
+            const int w = lv.W[0];
+            float* dp = dpa.p[0] + (int64_t)bi * lv.H[0] * w + o0;
+#pragma unroll
+            for (int yy = 0; yy < W0; ++yy)
+#pragma unroll
+                for (int xx = 0; xx < W0; ++xx) unsafeAtomicAdd(dp + yy * w + xx, total(yy * W0 + xx, d0[yy * W0 + xx]));
+        }
+        if constexpr (NF >= 2) {
+            const int w = lv.W[1];
+            float* dp = dpa.p[1] + (int64_t)bi * lv.H[1] * w + o1;
+#pragma unroll
+            for (int yy = 0; yy < W1; ++yy)
+#pragma unroll
+                for (int xx = 0; xx < W1; ++xx)
+                    unsafeAtomicAdd(dp + yy * w + xx, total(W0 * W0 + yy * W1 + xx, d1[yy * W1 + xx]));
+        }
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            const int i = NF + k;
+            if (i < lv.n && vc[k])
+                unsafeAtomicAdd(dpa.p[i] + (int64_t)bi * lv.H[i] * lv.W[i] + oc[k], total(W0 * W0 + W1 * W1 + k, dc[k]));
+        }
+    }
+    (void)ND;
+}
+
+// =========================================================================================================
 // backward C: dx = g + conv3x3^T(dpre_a; w1) + conv3x3^T(dpre_b; w2) + gather^T(dm / n)
 //   block = 64 pixel quads x 4 waves; a thread keeps the 3x6 neighbourhood of BOTH 1-channel gradient maps in
 //   registers (they do not depend on the channel) and each wave handles IB_CG consecutive channels: per channel one 16-B
@@ -1025,6 +1218,30 @@ extern "C" int32_t arfe_fpn_scatter_bwd(const arfe_pyramid_t* pyr, const float* 
                        fill_ptrs(dap, dpre_a, lv.n) && fill_ptrs(dbp, dpre_b, lv.n) && bsf && dbsf,
                    ARFE_ERR_ARG, "fpn_scatter_bwd: null pointer");
     hipStream_t st = as_stream(stream);
+    {   // single-pass form: the r finer levels are exactly 2^(r-i) times the refine level, r <= 2 (see the kernel)
+        bool fused = lv.r <= 2 && lv.n <= ARFE_MAX_LEVELS;
+        for (int i = 0; i < lv.r; ++i) fused = fused && lv.sh[i] == lv.r - i;
+        static const char* sw = getenv("ARFE_FPN_BWD_FUSED");
+        if (sw && sw[0] == '0') fused = false;
+        if (fused) {
+            ZeroList z;
+            for (int i = 0; i < lv.n; ++i) z.add(dap.p[i], (int64_t)lv.B * lv.H[i] * lv.W[i]);
+            rc = zero_buffers(z, st);
+            if (rc) return rc;
+            const int npx = lv.H[lv.r] * lv.W[lv.r];
+            const int nchunk = lv.C >= 128 ? 4 : (lv.C >= 32 ? 2 : 1);
+            dim3 grid((unsigned)(cdiv(npx, 64) * lv.B), nchunk);
+            if (lv.r == 2) hipLaunchKernelGGL((fpn_scatter_bwd_fused_kernel<2>), grid, dim3(256), 0, st, lv, gp, bsf, ap, bp, dap, dbsf);
+            else if (lv.r == 1) hipLaunchKernelGGL((fpn_scatter_bwd_fused_kernel<1>), grid, dim3(256), 0, st, lv, gp, bsf, ap, bp, dap, dbsf);
+            else hipLaunchKernelGGL((fpn_scatter_bwd_fused_kernel<0>), grid, dim3(256), 0, st, lv, gp, bsf, ap, bp, dap, dbsf);
+            ARFE_CHECK_LAUNCH();
+            TileTable tt = make_tile_table(lv);
+            hipLaunchKernelGGL(fpn_scatter_bwd_maps_finish_kernel, dim3((unsigned)cdiv64(tt.px_off[lv.n], 256)), dim3(256), 0, st,
+                               lv, tt, ap, bp, dap, dbp);
+            ARFE_CHECK_LAUNCH();
+            return ARFE_OK;
+        }
+    }
     PixQuadTable pt = make_pixquad_table(lv);
     const int nchunk = lv.C >= 64 ? 4 : 1;
     if (nchunk > 1) {
