@@ -230,12 +230,12 @@ class ARFPNFunction(torch.autograd.Function):
         w1, b1, w2, b2 = ([v.contiguous() for v in l] for l in (w1, b1, w2, b2))
         need_grad = any(ctx.needs_input_grad)
         dev = xs[0].device
-        # the gate maps depend only on the inputs: they stream the pyramid on the side stream while the NonLocal
-        # contractions (matrix-pipe bound, 0.4 ms) run on the main one.  The side stream is released AFTER the gather: both
-        # kernels stream the whole pyramid, and side by side they only halve each other's bandwidth while the NonLocal
-        # block waits for the gather (83 us instead of 48).
-        m, argmax = fpn_gather_op(xs, refine_level, want_argmax=need_grad)
+        # the gate maps depend only on the inputs: they stream the pyramid on the side stream while the small
+        # NonLocal contractions (which cannot fill the chip) run on the main one.  (Releasing the side stream only after
+        # the gather was measured: the gather drops from 83 to 62 us, but the gate MFMA kernel then shares the chip with the
+        # six-MFMA logit contractions, which lose 55 us - the neck forward ended 35 us later.)
         a, b = on_side(dev, lambda: fpn_gatemap_op(xs, w1, b1, w2, b2, refine_level))
+        m, argmax = fpn_gather_op(xs, refine_level, want_argmax=need_grad)
         bsf, saved = nonlocal_fwd_op(m, wt, bt, wp, bp, wg, bg, wo, bo)
         join_side(dev)
         outs = fpn_scatter_op(xs, bsf, a, b, refine_level)
