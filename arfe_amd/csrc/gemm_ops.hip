@@ -728,48 +728,74 @@ extern "C" int32_t arfe_nonlocal_fwd(int32_t B, int32_t C, int32_t L, const floa
     return ARFE_OK;
 }
 
-extern "C" int32_t arfe_nonlocal_bwd(int32_t B, int32_t C, int32_t L, const float* dbsf, const float* m,
-                                     const float* w_theta, const float* w_phi, const float* w_g, const float* w_out,
-                                     const float* tpg, const float* P, const float* y, float* dP, float* dm,
-                                     float* dw_theta, float* db_theta, float* dw_phi, float* db_phi, float* dw_g,
-                                     float* db_g, float* dw_out, float* db_out, void* workspace, void* stream) {
-    ARFE_CHECK_ARG(B > 0 && C > 0 && L > 0 && L <= 256 * NL_ROW_REGS, ARFE_ERR_ARG, "nonlocal_bwd: bad shape");
-    ARFE_CHECK_ARG(dbsf && m && w_theta && w_phi && w_g && w_out && tpg && P && y && dP && dm && dw_theta && db_theta &&
-                       dw_phi && db_phi && dw_g && db_g && dw_out && db_out && workspace,
-                   ARFE_ERR_ARG, "nonlocal_bwd: null pointer");
+// Workspace layout shared by the three parts of the backward (arfe_nonlocal_workspace_bytes):
+//   wcat [3C*C] | bcat [3C] | dwcat [3C*C] | dbcat [3C] | dtpg [B,3C,L] | dy [B,C,L] | delta [B,L]
+namespace {
+struct NlWs { float *wcat, *bcat, *dwcat, *dbcat, *dtpg, *dy, *delta; };
+NlWs nl_ws(void* workspace, int B, int C, int L) {
+    NlWs w;
+    const int64_t CL = (int64_t)C * L;
+    w.wcat = (float*)workspace;
+    w.bcat = w.wcat + (size_t)3 * C * C;
+    w.dwcat = w.bcat + (size_t)3 * C;
+    w.dbcat = w.dwcat + (size_t)3 * C * C;
+    w.dtpg = w.dbcat + (size_t)3 * C;
+    w.dy = w.dtpg + (size_t)B * 3 * CL;
+    w.delta = w.dy + (size_t)B * CL;
+    return w;
+}
+}  // namespace
+
+// dw_out, db_out: need only dbsf and the forward's y, i.e. nothing of the data path below
+extern "C" int32_t arfe_nonlocal_bwd_wout(int32_t B, int32_t C, int32_t L, const float* dbsf, const float* y, float* dw_out,
+                                          float* db_out, void* stream) {
+    ARFE_CHECK_ARG(B > 0 && C > 0 && L > 0, ARFE_ERR_ARG, "nonlocal_bwd_wout: bad shape");
+    ARFE_CHECK_ARG(dbsf && y && dw_out && db_out, ARFE_ERR_ARG, "nonlocal_bwd_wout: null pointer");
     hipStream_t st = as_stream(stream);
-    const int64_t CL = (int64_t)C * L, LL = (int64_t)L * L;
-    float* wcat = (float*)workspace;
-    float* bcat = wcat + (size_t)3 * C * C;
-    float* dwcat = bcat + (size_t)3 * C;
-    float* dbcat = dwcat + (size_t)3 * C * C;
-    float* dtpg = dbcat + (size_t)3 * C;
-    float* dy = dtpg + (size_t)B * 3 * CL;
-    float* delta = dy + (size_t)B * CL;
-    hipLaunchKernelGGL(nl_pack_kernel, dim3(cdiv(3 * C * C, 256)), dim3(256), 0, st, w_theta, w_phi, w_g,
-                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, wcat, (float*)nullptr, C);
-    ARFE_CHECK_LAUNCH();
+    const int64_t CL = (int64_t)C * L;
     int32_t rc;
     {
         ZeroList z;
-        z.add(dwcat, (int64_t)3 * C * C + 3 * C);
-        z.add(dtpg, (int64_t)B * 3 * CL);
         z.add(dw_out, (int64_t)C * C);
         z.add(db_out, C);
         rc = zero_buffers(z, st);
         if (rc) return rc;
     }
     const int kstepsL = cdiv(L, gemm_bk());
-    {   // dw_out[co][ci] = sum_{z,l} dbsf[z][co][l] y[z][ci][l]   (k-batched over images, split-K)
-        LoadRowMajorK la{dbsf, 0, CL, L, C, L};
-        LoadRowMajorK lb{y, 0, CL, L, C, L};
-        EpiPlain e = epi_plain(dw_out, 0, C);
-        e.atomic = 1;
-        rc = launch_gemm_auto(C, C, L, B, 1, pick_splitk(C, C, 1, B * kstepsL), la, lb, e, st);
+    // dw_out[co][ci] = sum_{z,l} dbsf[z][co][l] y[z][ci][l]   (k-batched over images, split-K)
+    LoadRowMajorK la{dbsf, 0, CL, L, C, L};
+    LoadRowMajorK lb{y, 0, CL, L, C, L};
+    EpiPlain e = epi_plain(dw_out, 0, C);
+    e.atomic = 1;
+    rc = launch_gemm_auto(C, C, L, B, 1, pick_splitk(C, C, 1, B * kstepsL), la, lb, e, st);
+    if (rc) return rc;
+    dim3 grid(C, B);
+    hipLaunchKernelGGL(reduce_mid_kernel, grid, dim3(256), 0, st, dbsf, (const float*)nullptr, db_out, B, CL, L, 1);
+    ARFE_CHECK_LAUNCH();
+    return ARFE_OK;
+}
+
+// the data path: dm = dbsf + [Wt;Wp;Wg]^T d(tpg); leaves d(tpg) in the workspace for arfe_nonlocal_bwd_wcat
+extern "C" int32_t arfe_nonlocal_bwd_data(int32_t B, int32_t C, int32_t L, const float* dbsf, const float* w_theta,
+                                          const float* w_phi, const float* w_g, const float* w_out, const float* tpg,
+                                          const float* P, const float* y, float* dP, float* dm, void* workspace,
+                                          void* stream) {
+    ARFE_CHECK_ARG(B > 0 && C > 0 && L > 0 && L <= 256 * NL_ROW_REGS, ARFE_ERR_ARG, "nonlocal_bwd: bad shape");
+    ARFE_CHECK_ARG(dbsf && w_theta && w_phi && w_g && w_out && tpg && P && y && dP && dm && workspace, ARFE_ERR_ARG,
+                   "nonlocal_bwd: null pointer");
+    hipStream_t st = as_stream(stream);
+    const int64_t CL = (int64_t)C * L, LL = (int64_t)L * L;
+    const NlWs ws = nl_ws(workspace, B, C, L);
+    float *wcat = ws.wcat, *dtpg = ws.dtpg, *dy = ws.dy, *delta = ws.delta;
+    hipLaunchKernelGGL(nl_pack_kernel, dim3(cdiv(3 * C * C, 256)), dim3(256), 0, st, w_theta, w_phi, w_g,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, wcat, (float*)nullptr, C);
+    ARFE_CHECK_LAUNCH();
+    int32_t rc;
+    {
+        ZeroList z;
+        z.add(dtpg, (int64_t)B * 3 * CL);
+        rc = zero_buffers(z, st);
         if (rc) return rc;
-        dim3 grid(C, B);
-        hipLaunchKernelGGL(reduce_mid_kernel, grid, dim3(256), 0, st, dbsf, (const float*)nullptr, db_out, B, CL, L, 1);
-        ARFE_CHECK_LAUNCH();
     }
     {   // dy[z][ci][l] = sum_co w_out[co][ci] dbsf[z][co][l]
         LoadRowMajorI la{w_out, 0, 0, C, C, C};
@@ -818,6 +844,28 @@ extern "C" int32_t arfe_nonlocal_bwd(int32_t B, int32_t C, int32_t L, const floa
         rc = gemm_autosplit(C, L, 3 * C, 1, B, la, lb, e, (size_t)B * CL, st);
         if (rc) return rc;
     }
+    return ARFE_OK;
+}
+
+// dw / db of theta, phi, g from the d(tpg) the data path left in the workspace
+extern "C" int32_t arfe_nonlocal_bwd_wcat(int32_t B, int32_t C, int32_t L, const float* m, float* dw_theta, float* db_theta,
+                                          float* dw_phi, float* db_phi, float* dw_g, float* db_g, void* workspace,
+                                          void* stream) {
+    ARFE_CHECK_ARG(B > 0 && C > 0 && L > 0, ARFE_ERR_ARG, "nonlocal_bwd_wcat: bad shape");
+    ARFE_CHECK_ARG(m && dw_theta && db_theta && dw_phi && db_phi && dw_g && db_g && workspace, ARFE_ERR_ARG,
+                   "nonlocal_bwd_wcat: null pointer");
+    hipStream_t st = as_stream(stream);
+    const int64_t CL = (int64_t)C * L;
+    const NlWs ws = nl_ws(workspace, B, C, L);
+    float *dwcat = ws.dwcat, *dbcat = ws.dbcat, *dtpg = ws.dtpg;
+    int32_t rc;
+    {
+        ZeroList z;
+        z.add(dwcat, (int64_t)3 * C * C + 3 * C);
+        rc = zero_buffers(z, st);
+        if (rc) return rc;
+    }
+    const int kstepsL = cdiv(L, gemm_bk());
     {   // dwcat[3C][C] = sum_{z,l} dtpg[z][.][l] m[z][.][l] ; dbcat = rowsum(dtpg)
         LoadRowMajorK la{dtpg, 0, 3 * CL, L, 3 * C, L};
         LoadRowMajorK lb{m, 0, CL, L, C, L};
@@ -833,4 +881,16 @@ extern "C" int32_t arfe_nonlocal_bwd(int32_t B, int32_t C, int32_t L, const floa
                        db_theta, db_phi, db_g, C);
     ARFE_CHECK_LAUNCH();
     return ARFE_OK;
+}
+
+extern "C" int32_t arfe_nonlocal_bwd(int32_t B, int32_t C, int32_t L, const float* dbsf, const float* m,
+                                     const float* w_theta, const float* w_phi, const float* w_g, const float* w_out,
+                                     const float* tpg, const float* P, const float* y, float* dP, float* dm,
+                                     float* dw_theta, float* db_theta, float* dw_phi, float* db_phi, float* dw_g,
+                                     float* db_g, float* dw_out, float* db_out, void* workspace, void* stream) {
+    int32_t rc = arfe_nonlocal_bwd_wout(B, C, L, dbsf, y, dw_out, db_out, stream);
+    if (rc) return rc;
+    rc = arfe_nonlocal_bwd_data(B, C, L, dbsf, w_theta, w_phi, w_g, w_out, tpg, P, y, dP, dm, workspace, stream);
+    if (rc) return rc;
+    return arfe_nonlocal_bwd_wcat(B, C, L, m, dw_theta, db_theta, dw_phi, db_phi, dw_g, db_g, workspace, stream);
 }

@@ -195,7 +195,10 @@ def nonlocal_fwd_op(m, wt, bt, wp, bp, wg, bg, wo, bo):
     return bsf, (tpg, P, y)
 
 
-def nonlocal_bwd_op(dbsf, m, wt, wp, wg, wo, saved):
+def nonlocal_bwd_op(dbsf, m, wt, wp, wg, wo, saved, split_streams=False):
+    """-> dm, (dwt, dbt, dwp, dbp, dwg, dbg, dwo, dbo).
+    split_streams: the two parameter-gradient parts go to the side stream (dw_out beside the data path, the theta / phi / g
+    gradients after it - beside whatever the caller enqueues next on the current stream); the CALLER joins the side stream."""
     tpg, P, y = saved
     hip.require_f32_cuda(dbsf, m, wt, wp, wg, wo, tpg, P, y)
     B, C, h, w = m.shape
@@ -206,11 +209,23 @@ def nonlocal_bwd_op(dbsf, m, wt, wp, wg, wo, saved):
     dwt, dwp, dwg, dwo = (torch.empty_like(t) for t in (wt, wp, wg, wo))
     dbt, dbp, dbg, dbo = (torch.empty(C, device=dev) for _ in range(4))
     ws = _ws(hip.lib().arfe_nonlocal_workspace_bytes(B, C, L), dev)
+    if not split_streams:
+        with probe('nonlocal_bwd'):
+            check(hip.lib().arfe_nonlocal_bwd(B, C, L, ptr(dbsf), ptr(m), ptr(wt), ptr(wp), ptr(wg), ptr(wo), ptr(tpg), ptr(P),
+                                              ptr(y), ptr(dP), ptr(dm), ptr(dwt), ptr(dbt), ptr(dwp), ptr(dbp), ptr(dwg),
+                                              ptr(dbg), ptr(dwo), ptr(dbo), ptr(ws), stream()), "arfe_nonlocal_bwd")
+        return dm, (dwt, dbt, dwp, dbp, dwg, dbg, dwo, dbo)
+    L_ = hip.lib()
+    on_side(dev, lambda: check(L_.arfe_nonlocal_bwd_wout(B, C, L, ptr(dbsf), ptr(y), ptr(dwo), ptr(dbo), stream()),
+                               "arfe_nonlocal_bwd_wout"))
     with probe('nonlocal_bwd'):
-        check(hip.lib().arfe_nonlocal_bwd(B, C, L, ptr(dbsf), ptr(m), ptr(wt), ptr(wp), ptr(wg), ptr(wo), ptr(tpg), ptr(P),
-                                          ptr(y), ptr(dP), ptr(dm), ptr(dwt), ptr(dbt), ptr(dwp), ptr(dbp), ptr(dwg),
-                                          ptr(dbg), ptr(dwo), ptr(dbo), ptr(ws), stream()), "arfe_nonlocal_bwd")
-    return dm, (dwt, dbt, dwp, dbp, dwg, dbg, dwo, dbo)
+        check(L_.arfe_nonlocal_bwd_data(B, C, L, ptr(dbsf), ptr(wt), ptr(wp), ptr(wg), ptr(wo), ptr(tpg), ptr(P), ptr(y),
+                                        ptr(dP), ptr(dm), ptr(ws), stream()), "arfe_nonlocal_bwd_data")
+    on_side(dev, lambda: check(L_.arfe_nonlocal_bwd_wcat(B, C, L, ptr(m), ptr(dwt), ptr(dbt), ptr(dwp), ptr(dbp), ptr(dwg),
+                                                         ptr(dbg), ptr(ws), stream()), "arfe_nonlocal_bwd_wcat"))
+    # (ws, dP and the outputs were allocated on the current stream and are used on the side stream: the caller's join
+    # orders every later use; `keep` holds them until then)
+    return dm, (dwt, dbt, dwp, dbp, dwg, dbg, dwo, dbo), (ws, dP)
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -259,9 +274,12 @@ class ARFPNFunction(torch.autograd.Function):
         dev = xs[0].device
         dpa, dpb, dbsf = fpn_scatter_bwd_op(gouts, bsf, a, b, r)
         dw1, db1, dw2, db2 = on_side(dev, lambda: fpn_gate_wgrad_op(xs, dpa, dpb, r))   # beside the NonLocal backward
-        dm, (dwt, dbt, dwp, dbp, dwg, dbg, dwo, dbo) = nonlocal_bwd_op(dbsf, m, wt, wp, wg, wo, saved)
+        # the NonLocal parameter gradients (five small latency-bound launches, 0.12 ms) leave the critical chain:
+        # dw_out runs beside the data path, the theta / phi / g gradients beside the HBM-bound input gradient below
+        dm, (dwt, dbt, dwp, dbp, dwg, dbg, dwo, dbo), keep = nonlocal_bwd_op(dbsf, m, wt, wp, wg, wo, saved, split_streams=True)
         dxs = fpn_input_bwd_op(gouts, dpa, dpb, w1, w2, dm, argmax, r)
         join_side(dev)
+        del keep
         return (None, None, *dxs, *dw1, *db1, *dw2, *db2, dwt, dbt, dwp, dbp, dwg, dbg, dwo, dbo)
 
 

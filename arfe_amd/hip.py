@@ -49,6 +49,9 @@ SIGNATURES = {
     "arfe_nonlocal_workspace_bytes": (_i64, [_i32, _i32, _i32]),
     "arfe_nonlocal_fwd": (_i32, [_i32, _i32, _i32] + [_vp] * 15),
     "arfe_nonlocal_bwd": (_i32, [_i32, _i32, _i32] + [_vp] * 21),
+    "arfe_nonlocal_bwd_wout": (_i32, [_i32, _i32, _i32] + [_vp] * 5),
+    "arfe_nonlocal_bwd_data": (_i32, [_i32, _i32, _i32] + [_vp] * 12),
+    "arfe_nonlocal_bwd_wcat": (_i32, [_i32, _i32, _i32] + [_vp] * 9),
     "arfe_rff_make_rois": (_i32, [_i32, _vp, _vp, _vp, _vp]),
     "arfe_map_roi_levels": (_i32, [_i32, _vp, _i32, _f32, _vp, _vp]),
     "arfe_rff_roi_sets": (_i32, [_i32, _vp, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),

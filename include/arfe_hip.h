@@ -111,6 +111,17 @@ int32_t arfe_nonlocal_bwd(int32_t B, int32_t C, int32_t L, const float* dbsf, co
                           float* dw_theta, float* db_theta, float* dw_phi, float* db_phi, float* dw_g,
                           float* db_g, float* dw_out, float* db_out, void* workspace, void* stream);
 
+/* The same backward in three calls, so that a caller can put the parameter gradients on a second stream beside the data
+ * path: _wout (dw_out, db_out: needs dbsf and y only), _data (dm; leaves d(theta|phi|g) in the workspace) and _wcat
+ * (the six theta / phi / g gradients from that workspace, after _data).  arfe_nonlocal_bwd == the three in a row. */
+int32_t arfe_nonlocal_bwd_wout(int32_t B, int32_t C, int32_t L, const float* dbsf, const float* y, float* dw_out,
+                               float* db_out, void* stream);
+int32_t arfe_nonlocal_bwd_data(int32_t B, int32_t C, int32_t L, const float* dbsf, const float* w_theta,
+                               const float* w_phi, const float* w_g, const float* w_out, const float* tpg, const float* P,
+                               const float* y, float* dP, float* dm, void* workspace, void* stream);
+int32_t arfe_nonlocal_bwd_wcat(int32_t B, int32_t C, int32_t L, const float* m, float* dw_theta, float* db_theta,
+                               float* dw_phi, float* db_phi, float* dw_g, float* db_g, void* workspace, void* stream);
+
 /* ======================================================================================================
  * AR-RFF
  * ==================================================================================================== */
