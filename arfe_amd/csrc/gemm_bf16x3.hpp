@@ -959,10 +959,19 @@ bool gemm_use_f32();
 // The 256x256 kernel pays when the output holds enough large tiles to occupy the chip (one 8-wave workgroup per
 // CU).  When the caller allows K-slicing (splitk > 1: atomic epilogue into a zeroed output) the slice count is
 // re-derived for the large tile so that tiles x slices is about one workgroup per CU.
-static inline bool plan_large_tile(int M, int N, int batch, int ksteps, int* splitk) {
+static inline bool plan_large_tile(int M, int N, int batch, int ksteps, int* splitk, bool caller_plans_k = false) {
     const int64_t tiles = (int64_t)cdiv(M, XL_BM) * cdiv(N, XL_BN) * batch;
     const double fill = (double)M * N / ((double)cdiv(M, XL_BM) * XL_BM * (double)cdiv(N, XL_BN) * XL_BN);
     if (fill < 0.85) return false;
+    // Round 2 (profiles/r02_gemm_sweep.txt): with its two LDS buffers the 128x128 kernel keeps two workgroups per CU busy
+    // at 1.23 tile-steps/us/CU against 1.08 for this one, and cuts K finer for less atomic traffic - FC1 (16 large tiles,
+    // K = 12544) 149 -> 114 us, the NonLocal K = L contractions 137 -> 118 us.  The 256-wide tile only pays where the
+    // output alone fills the chip AND the K loop is long enough to amortise its prologue (4096^3: 396 vs 528 us; the conv
+    // GEMMs), where the caller has planned the K ranges for it (per-batch lengths), or where one whole dimension fits in a
+    // single 256-tile: the NonLocal K = L contractions (M = 256 channels against the 70 MB attention matrix) read that
+    // matrix once with the large tile and twice with two rows of 128-tiles - measured in the step 113 vs 141 us.
+    const bool one_tile_dim = (M > GEMM_BM && M <= XL_BM) || (N > GEMM_BN && N <= XL_BN);
+    if (!caller_plans_k && !one_tile_dim && !(tiles >= 512 || (tiles >= 192 && ksteps >= 32))) return false;
     int sk = 1;
     if (*splitk > 1) {
         sk = (int)(256 / (tiles > 0 ? tiles : 1));
@@ -1014,7 +1023,7 @@ static inline int32_t launch_gemm_auto(int M, int N, int K, int kb_count, int ba
     if (splitk < 1) splitk = 1;
     if (splitk > d.ksteps_total && d.ksteps_total > 0) splitk = d.ksteps_total;
     int splitk_large = splitk;
-    bool use_large = plan_large_tile(M, N, batch, d.ksteps_total, &splitk_large);
+    bool use_large = plan_large_tile(M, N, batch, d.ksteps_total, &splitk_large, zvar != nullptr);
     {   // tuning aid (tools/gemm_sweep.py): ARFE_GEMM_PLAN=L<k> / S<k> forces the tile and, for callers that already
         // take the atomic split-K path, the slice count
         static const char* plan = getenv("ARFE_GEMM_PLAN");

@@ -281,8 +281,11 @@ static inline int32_t launch_gemm(int M, int N, int K, int kb_count, int batch, 
 }
 
 // how many K-slices to cut so that about one wave of workgroups per CU pair is in flight (256 CUs, 2 WG/CU)
-// K-slices for the 128x128 kernels, from a three-term cost model fitted to tools/gemm_sweep.py on MI355X (us):
-//   rounds(tiles * s over 2 workgroups per CU) * (K-steps per slice * 1.8 + 8 fixed)  +  atomic bytes / 1.3 TB/s
+// K-slices for the 128x128 kernels, from a cost model fitted to tools/gemm_sweep.py on MI355X (us), round 2 (the
+// double-buffered kernel; profiles/r02_gemm_sweep.txt):
+//   rounds * (K-steps per slice * t_step + 20 fixed)  +  atomic bytes / 1.3 TB/s
+//   t_step = 1.1 us while every workgroup has a CU to itself (<= 256), 1.65 us with two per CU; rounds = workgroups / 512
+//   beyond one full wave of two workgroups per CU (fractional: the tail overlaps the next round)
 // Small outputs (cls / reg / bias-sized) take many thin slices, large ones few (their atomic traffic dominates).
 static inline int pick_splitk(int M, int N, int batch, int ksteps) {
     const int64_t tiles = (int64_t)cdiv(M, GEMM_BM) * cdiv(N, GEMM_BN) * batch;
@@ -293,8 +296,10 @@ static inline int pick_splitk(int M, int N, int batch, int ksteps) {
     static const int cand[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128};
     for (int s : cand) {
         if (s > 1 && s * 2 > ksteps) break;                 // at least 2 K-steps per slice
-        const double rounds = (double)cdiv64(tiles * s, 512);
-        const double t = rounds * ((double)cdiv(ksteps, s) * 1.8 + 8.0) + (s > 1 ? out_bytes * s / 1.3e6 : 0.0);
+        const double wgs = (double)tiles * s;
+        const double t_step = wgs <= 256.0 ? 1.1 : 1.65;
+        const double rounds = wgs <= 512.0 ? 1.0 : wgs / 512.0;
+        const double t = rounds * ((double)cdiv(ksteps, s) * t_step + 20.0) + (s > 1 ? out_bytes * s / 1.3e6 : 0.0);
         if (t < best) { best = t; best_s = s; }
     }
     return best_s;

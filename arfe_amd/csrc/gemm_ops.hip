@@ -601,7 +601,7 @@ extern "C" int32_t arfe_conv3x3_bwd_weight(int32_t R, int32_t C, const float* x,
     const int bk = gemm_bk();
     const int steps7 = cdiv(R * 56, bk), steps6 = cdiv(R * 48, bk);
     int sk_probe = 64;
-    const bool zvar = !gemm_use_f32() && plan_large_tile(C, C, 9, steps7, &sk_probe);
+    const bool zvar = !gemm_use_f32() && plan_large_tile(C, C, 9, steps7, &sk_probe, /*caller_plans_k=*/true);
     WgradA la{dy, dy_roi_stride, C, R, zvar ? 0 : 1};
     WgradB lb{x, x_roi_stride, C, R, zvar ? 0 : 1};
     EpiPlain e = epi_plain(dwp, (int64_t)C * C, C);
