@@ -93,6 +93,30 @@ def test_scatter_matches_oracle(Fn, O, dev, shape, r):
         assert relerr(outs[i], ref) <= 1e-6, i
 
 
+@pytest.mark.parametrize('shape', list(PYRAMIDS))
+@pytest.mark.parametrize('r,C', [(0, 9), (1, 70), (2, 9), (2, 70), (2, 256), (3, 33), (4, 9)])
+def test_scatter_bwd_matches_oracle_autograd(Fn, O, dev, shape, r, C):
+    """arfe_fpn_scatter_bwd (dpre_a, dpre_b, dbsf) against autograd of the oracle's scatter on every refine level: the
+    single-pass kernel (`fpn_scatter_bwd_fused_kernel<0|1|2>`: 'tiny' / 'mid' pyramids with r <= 2, all three channel
+    chunkings) and the two-kernel form (ragged / odd pyramids, r = 3, 4)."""
+    g = torch.Generator().manual_seed(40 + r)
+    sizes = PYRAMIDS[shape]
+    bsf = torch.randn(2, C, *sizes[r], generator=g).requires_grad_(True)
+    pa = [torch.randn(2, 1, h, w, generator=g).requires_grad_(True) for h, w in sizes]
+    pb = [torch.randn(2, 1, h, w, generator=g).requires_grad_(True) for h, w in sizes]
+    a = [torch.tanh(torch.relu(t)) for t in pa]
+    b = [torch.tanh(torch.relu(t)) for t in pb]
+    cots = [torch.randn(2, C, h, w, generator=g) for h, w in sizes]
+    loss = sum((O.fpn_scatter(torch.zeros(2, C, h, w), bsf, a[i], b[i], explicit=True) * cots[i]).sum()
+               for i, (h, w) in enumerate(sizes))
+    loss.backward()
+    dpa, dpb, dbsf = Fn.fpn_scatter_bwd_op(cu(cots, dev), bsf.detach().to(dev), cu([t.detach() for t in a], dev),
+                                           cu([t.detach() for t in b], dev), r)
+    assert relerr(dbsf, bsf.grad) <= 2e-5
+    for i in range(5):
+        assert relerr(dpa[i], pa[i].grad) <= 2e-5 and relerr(dpb[i], pb[i].grad) <= 2e-5, i
+
+
 @pytest.mark.parametrize('B,C,h,w', [(1, 8, 4, 6), (2, 16, 10, 17), (1, 256, 13, 21), (2, 64, 25, 42)])
 def test_nonlocal_fwd_bwd_matches_oracle(Fn, O, dev, B, C, h, w):
     g = torch.Generator().manual_seed(4)
@@ -864,6 +888,22 @@ def test_shape_sweep_in_default_bf16x3_mode():
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert out.stdout.count('case ') == 5
+
+
+def test_two_kernel_arfpn_backward_with_the_fused_pass_switched_off():
+    """ARFE_FPN_BWD_FUSED=0 keeps the round-1 form (maps kernel + dbsf kernel) that ragged pyramids and refine levels 3 / 4
+    still take; the golden AR-FPN cases and the neck sequence must pass through it as well (fresh process: the switch is
+    read once)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, ARFE_FPN_BWD_FUSED='0')
+    out = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(ROOT, 'tests', 'test_gpu_parity.py'), '-q', '-x', '-m', 'gpu',
+                          '-k', 'arfpn_golden or neck_sequence or end_to_end_golden'], env=env, cwd=ROOT, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert ' passed' in out.stdout
 
 
 def test_generic_conv_kernels_with_stage_once_switched_off():
