@@ -271,6 +271,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmDims d, LA la, 
     } else if (!first_split) {
         return;
     }
+    epi_select_slice(epi, (int)blockIdx.y);
 
     const int h = lane >> 5;
 #pragma unroll
@@ -691,6 +692,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_large_kernel(GemmDims d, L
     } else if (!first_split) {
         return;
     }
+    epi_select_slice(epi, slice);
 
     // D layout of a 32x32 block: lane -> column l31, register r -> row (r & 3) + 8 (r >> 2) + 4 (lane >> 5).  The two
     // column blocks of a wave exchange halves (v_permlane32_swap: upper lanes of the first with lower lanes of the
@@ -915,6 +917,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_n224_kernel(GemmDims d, LA
     } else if (!first_split) {
         return;
     }
+    epi_select_slice(epi, (int)blockIdx.y);
     // D layout: lane -> column l15, rows 4*lq + r
     if constexpr (epi_has_rowbias<EPI>::value) {       // the 16 rows' biases first, then nothing but stores
         float rb[4][4];

@@ -126,8 +126,13 @@ struct EpiPlain {   // C[z*sz + m*ld + n] ; optional bias per row (m) or per col
     // optional softmax backward folded into the producer of dP (no split-K): C = scale[o] * (v - rowsub[z*rowsub_sz + m]),
     // i.e. dS = P * (dP - delta) with delta the per-row sum of P * dP (computed from the outputs, see nl_rowdot_kernel)
     const float* scale = nullptr; const float* rowsub = nullptr; int64_t rowsub_sz = 0;
+    // split-K without atomics: slice s stores its raw partial sums into slab s (c + s * slab_stride, selected by the
+    // kernel through epi_select_slice) and gemm_slab_reduce_kernel sums the slabs, then applies bias / residual / ReLU /
+    // mask.  0 = off (atomic adds into a zeroed c, or no split at all).
+    int64_t slab_stride = 0;
     __device__ __forceinline__ void operator()(int z, int m, int n, float v, bool first_split) const {
         int64_t o = z * sz + (int64_t)m * ld + n;
+        if (slab_stride) { c[o] = v; return; }
         if (first_split) {
             if (bias_m) v += epi_ld(bias_m, m);
             if (bias_n) v += epi_ld(bias_n, n);
@@ -153,6 +158,11 @@ struct EpiPlain {   // C[z*sz + m*ld + n] ; optional bias per row (m) or per col
     }
 };
 template <> struct epi_has_pre<EpiPlain> { static constexpr bool value = true; };
+// hook called by the split-K kernels with their K-slice index before the epilogue (a no-op for other epilogues)
+template <class EPI> __device__ __forceinline__ void epi_select_slice(EPI&, int) {}
+__device__ __forceinline__ void epi_select_slice(EpiPlain& e, int slice) {
+    if (e.slab_stride) e.c += (int64_t)slice * e.slab_stride;
+}
 
 template <class LA, class LB, class EPI>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmDims d, LA la, LB lb, EPI epi) {

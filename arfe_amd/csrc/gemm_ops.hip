@@ -370,10 +370,72 @@ static inline EpiPlain epi_plain(float* c, int64_t sz, int64_t ld) {
 
 // GEMM whose output region (zero_elems floats from e.c) may be cut along K when the tile count alone cannot
 // fill the chip: the output is zeroed and the slices add atomically (bias/residual enter with slice 0).
+// out[o] = epilogue(sum_s slabs[s * stride + o]) over the GEMM's output elements o = z*sz + m*ld + n: the second half of a
+// slab-mode split-K (EpiPlain::slab_stride).  One thread per 4 consecutive n (16-byte reads when the row allows).
+__global__ __launch_bounds__(256) void gemm_slab_reduce_kernel(const float* __restrict__ slabs, int nslabs, int64_t stride,
+                                                               int M, int N, int batch, EpiPlain e) {
+    const int nq = (N + 3) / 4;
+    const int64_t total = (int64_t)batch * M * nq;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int q = (int)(i % nq);
+    const int m = (int)((i / nq) % M);
+    const int z = (int)(i / ((int64_t)nq * M));
+    const int n0 = q * 4;
+    const int64_t o = z * e.sz + (int64_t)m * e.ld + n0;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool vec = n0 + 3 < N && ((o | stride) & 3) == 0 && (((uintptr_t)slabs) & 15) == 0;
+    for (int k = 0; k < nslabs; ++k) {
+        const float* p = slabs + (int64_t)k * stride + o;
+        if (vec) {
+            const float4_u v = *reinterpret_cast<const float4_u*>(p);
+            s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+        } else {
+            for (int t = 0; t < 4 && n0 + t < N; ++t) s[t] += p[t];
+        }
+    }
+    for (int t = 0; t < 4 && n0 + t < N; ++t) {
+        float v = s[t];
+        if (e.bias_m) v += e.bias_m[m];
+        if (e.bias_n) v += e.bias_n[n0 + t];
+        if (e.residual) v += e.residual[o + t];
+        if (e.accumulate) v += e.c[o + t];
+        if (e.relu) v = fmaxf(v, 0.f);
+        if (e.mask && !(e.mask[o + t] > 0.f)) v = 0.f;
+        e.c[o + t] = v;
+    }
+}
+
+// slabs / slab_floats: optional scratch for the atomic-free split-K (see gemm_slab_reduce_kernel); when it is too small for
+// the planned slice count the atomic form is used.
 template <class LA, class LB>
 static inline int32_t gemm_autosplit(int M, int N, int K, int kb, int batch, LA la, LB lb, EpiPlain e,
-                                     size_t zero_elems, hipStream_t st) {
-    int splitk = (e.relu || e.accumulate) ? 1 : pick_splitk(M, N, batch, (kb < 1 ? 1 : kb) * cdiv(K, gemm_bk()));
+                                     size_t zero_elems, hipStream_t st, float* slabs = nullptr, int64_t slab_floats = 0) {
+    const int ksteps = (kb < 1 ? 1 : kb) * cdiv(K, gemm_bk());
+    int splitk = (e.relu || e.accumulate) ? 1 : pick_splitk(M, N, batch, ksteps);
+    static const char* plan_env = getenv("ARFE_GEMM_PLAN");        // a forced plan bypasses the planner replicated below
+    if (slabs && !gemm_use_f32() && !e.scale && !plan_env) {
+        // the slice count the launcher will settle on (same planner calls as launch_gemm_auto)
+        int req = pick_splitk(M, N, batch, ksteps);
+        int sk_large = req;
+        const bool large = plan_large_tile(M, N, batch, ksteps, &sk_large);
+        int final_sk = large ? sk_large : req;
+        if (final_sk > ksteps) final_sk = ksteps;
+        const int nslabs = final_sk > 1 ? cdiv(ksteps, cdiv(ksteps, final_sk)) : 1;
+        const int64_t region = (((int64_t)(batch - 1) * e.sz + (int64_t)(M - 1) * e.ld + N) + 3) & ~(int64_t)3;
+        if (nslabs > 1 && (int64_t)nslabs * region <= slab_floats) {
+            EpiPlain part = e;
+            part.c = slabs; part.slab_stride = region;
+            part.bias_m = part.bias_n = part.residual = part.mask = nullptr; part.relu = part.accumulate = part.atomic = 0;
+            int32_t rc = launch_gemm_auto(M, N, K, kb, batch, req, la, lb, part, st);
+            if (rc) return rc;
+            const int64_t total = (int64_t)batch * M * ((N + 3) / 4);
+            hipLaunchKernelGGL(gemm_slab_reduce_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, (const float*)slabs,
+                               nslabs, region, M, N, batch, e);
+            ARFE_CHECK_LAUNCH();
+            return ARFE_OK;
+        }
+    }
     if (splitk > 1) {
         if (hipMemsetAsync(e.c, 0, sizeof(float) * zero_elems, st) != hipSuccess) {
             set_error("gemm: memset failed");
@@ -666,10 +728,22 @@ extern "C" int32_t arfe_conv3x3_bwd_weight(int32_t R, int32_t C, const float* x,
 // =========================================================================================================
 // NonLocal2D
 // =========================================================================================================
+constexpr int NL_SLABS = 8;
+static inline int64_t nl_slab_region(int B, int C, int L) {
+    return ((((int64_t)(B - 1) * 3 + 1) * C * L) + 3) & ~(int64_t)3;
+}
+static inline int64_t nl_slab_floats(int B, int C, int L) { return (int64_t)NL_SLABS * nl_slab_region(B, C, L); }
+static inline float* nl_slab_base(void* workspace, int B, int C, int L) {
+    int64_t f = (int64_t)2 * (3 * C * C + 3 * C) + (int64_t)B * 3 * C * L + (int64_t)B * C * L + (int64_t)B * L;
+    f = (f + 3) & ~(int64_t)3;
+    return (float*)workspace + f;
+}
 extern "C" int64_t arfe_nonlocal_workspace_bytes(int32_t B, int32_t C, int32_t L) {
     // wcat (3C*C) + bcat (3C) + dwcat (3C*C) + dbcat (3C) + dtpg [B,3C,L] + dy [B,C,L] + delta [B,L]
+    // + NL_SLABS partial-sum slabs for the K = L contractions' split-K (each spans one [C, L] slice of a [B, 3C, L] tensor)
     int64_t f = (int64_t)2 * (3 * C * C + 3 * C) + (int64_t)B * 3 * C * L + (int64_t)B * C * L + (int64_t)B * L;
-    return f * (int64_t)sizeof(float) + 256;
+    f = (f + 3) & ~(int64_t)3;
+    return (f + nl_slab_floats(B, C, L)) * (int64_t)sizeof(float) + 256;
 }
 
 extern "C" int32_t arfe_nonlocal_fwd(int32_t B, int32_t C, int32_t L, const float* m, const float* w_theta,
@@ -713,7 +787,7 @@ extern "C" int32_t arfe_nonlocal_fwd(int32_t B, int32_t C, int32_t L, const floa
         LoadRowMajorK la{tpg + 2 * CL, 3 * CL, 0, L, C, L};
         LoadRowMajorK lb{P, LL, 0, L, L, L};
         EpiPlain e = epi_plain(y, CL, L);
-        rc = gemm_autosplit(C, L, L, 1, B, la, lb, e, (size_t)B * CL, st);
+        rc = gemm_autosplit(C, L, L, 1, B, la, lb, e, (size_t)B * CL, st, nl_slab_base(workspace, B, C, L), nl_slab_floats(B, C, L));
         if (rc) return rc;
     }
     {   // bsf[z] = m[z] + w_out . y[z] + b_out
@@ -819,21 +893,21 @@ extern "C" int32_t arfe_nonlocal_bwd_data(int32_t B, int32_t C, int32_t L, const
         LoadRowMajorK la{dy, CL, 0, L, C, L};
         LoadRowMajorI lb{P, LL, 0, L, L, L};
         EpiPlain e = epi_plain(dtpg + 2 * CL, 3 * CL, L);
-        rc = gemm_autosplit(C, L, L, 1, B, la, lb, e, 0, st);
+        rc = gemm_autosplit(C, L, L, 1, B, la, lb, e, 0, st, nl_slab_base(workspace, B, C, L), nl_slab_floats(B, C, L));
         if (rc) return rc;
     }
     {   // dtheta[z][c][i] = sum_j dS[i][j] phi[c][j]
         LoadRowMajorK la{tpg + CL, 3 * CL, 0, L, C, L};
         LoadRowMajorK lb{dP, LL, 0, L, L, L};
         EpiPlain e = epi_plain(dtpg, 3 * CL, L);
-        rc = gemm_autosplit(C, L, L, 1, B, la, lb, e, 0, st);
+        rc = gemm_autosplit(C, L, L, 1, B, la, lb, e, 0, st, nl_slab_base(workspace, B, C, L), nl_slab_floats(B, C, L));
         if (rc) return rc;
     }
     {   // dphi[z][c][j] = sum_i dS[i][j] theta[c][i]
         LoadRowMajorK la{tpg, 3 * CL, 0, L, C, L};
         LoadRowMajorI lb{dP, LL, 0, L, L, L};
         EpiPlain e = epi_plain(dtpg + CL, 3 * CL, L);
-        rc = gemm_autosplit(C, L, L, 1, B, la, lb, e, 0, st);
+        rc = gemm_autosplit(C, L, L, 1, B, la, lb, e, 0, st, nl_slab_base(workspace, B, C, L), nl_slab_floats(B, C, L));
         if (rc) return rc;
     }
     {   // dm[z] = dbsf[z] + wcat^T . dtpg[z]
