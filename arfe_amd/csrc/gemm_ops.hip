@@ -406,36 +406,50 @@ __global__ __launch_bounds__(256) void gemm_slab_reduce_kernel(const float* __re
     }
 }
 
-// slabs / slab_floats: optional scratch for the atomic-free split-K (see gemm_slab_reduce_kernel); when it is too small for
-// the planned slice count the atomic form is used.
+// Split-K with per-slice slabs when the planner wants K slices and the scratch holds them: the GEMM stores raw partial
+// sums, gemm_slab_reduce_kernel applies `e` (bias, residual, accumulate, ReLU, mask all allowed).  *done = false: nothing was
+// launched (no split planned, scratch too small, exact-fp32 / forced-plan mode) and the caller takes its other path.
+template <class LA, class LB>
+static inline int32_t gemm_try_slabs(int M, int N, int K, int kb, int batch, LA la, LB lb, const EpiPlain& e, hipStream_t st,
+                                     float* slabs, int64_t slab_floats, bool* done) {
+    *done = false;
+    static const char* plan_env = getenv("ARFE_GEMM_PLAN");        // a forced plan bypasses the planner replicated below
+    if (!slabs || gemm_use_f32() || e.scale || plan_env) return ARFE_OK;
+    const int ksteps = (kb < 1 ? 1 : kb) * cdiv(K, gemm_bk());
+    // the slice count the launcher will settle on (same planner calls as launch_gemm_auto)
+    const int req = pick_splitk(M, N, batch, ksteps);
+    int sk_large = req;
+    const bool large = plan_large_tile(M, N, batch, ksteps, &sk_large);
+    int final_sk = large ? sk_large : req;
+    if (final_sk > ksteps) final_sk = ksteps;
+    const int nslabs = final_sk > 1 ? cdiv(ksteps, cdiv(ksteps, final_sk)) : 1;
+    const int64_t region = (((int64_t)(batch - 1) * e.sz + (int64_t)(M - 1) * e.ld + N) + 3) & ~(int64_t)3;
+    if (nslabs <= 1 || (int64_t)nslabs * region > slab_floats) return ARFE_OK;
+    EpiPlain part = e;
+    part.c = slabs; part.slab_stride = region;
+    part.bias_m = part.bias_n = part.residual = part.mask = nullptr; part.relu = part.accumulate = part.atomic = 0;
+    int32_t rc = launch_gemm_auto(M, N, K, kb, batch, req, la, lb, part, st);
+    if (rc) return rc;
+    const int64_t total = (int64_t)batch * M * ((N + 3) / 4);
+    hipLaunchKernelGGL(gemm_slab_reduce_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, (const float*)slabs, nslabs,
+                       region, M, N, batch, e);
+    ARFE_CHECK_LAUNCH();
+    *done = true;
+    return ARFE_OK;
+}
+
+// slabs / slab_floats: optional scratch for the atomic-free split-K above; otherwise (or when it is too small for the planned
+// slice count) the output is zeroed and the slices add atomically.
 template <class LA, class LB>
 static inline int32_t gemm_autosplit(int M, int N, int K, int kb, int batch, LA la, LB lb, EpiPlain e,
                                      size_t zero_elems, hipStream_t st, float* slabs = nullptr, int64_t slab_floats = 0) {
     const int ksteps = (kb < 1 ? 1 : kb) * cdiv(K, gemm_bk());
-    int splitk = (e.relu || e.accumulate) ? 1 : pick_splitk(M, N, batch, ksteps);
-    static const char* plan_env = getenv("ARFE_GEMM_PLAN");        // a forced plan bypasses the planner replicated below
-    if (slabs && !gemm_use_f32() && !e.scale && !plan_env) {
-        // the slice count the launcher will settle on (same planner calls as launch_gemm_auto)
-        int req = pick_splitk(M, N, batch, ksteps);
-        int sk_large = req;
-        const bool large = plan_large_tile(M, N, batch, ksteps, &sk_large);
-        int final_sk = large ? sk_large : req;
-        if (final_sk > ksteps) final_sk = ksteps;
-        const int nslabs = final_sk > 1 ? cdiv(ksteps, cdiv(ksteps, final_sk)) : 1;
-        const int64_t region = (((int64_t)(batch - 1) * e.sz + (int64_t)(M - 1) * e.ld + N) + 3) & ~(int64_t)3;
-        if (nslabs > 1 && (int64_t)nslabs * region <= slab_floats) {
-            EpiPlain part = e;
-            part.c = slabs; part.slab_stride = region;
-            part.bias_m = part.bias_n = part.residual = part.mask = nullptr; part.relu = part.accumulate = part.atomic = 0;
-            int32_t rc = launch_gemm_auto(M, N, K, kb, batch, req, la, lb, part, st);
-            if (rc) return rc;
-            const int64_t total = (int64_t)batch * M * ((N + 3) / 4);
-            hipLaunchKernelGGL(gemm_slab_reduce_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, (const float*)slabs,
-                               nslabs, region, M, N, batch, e);
-            ARFE_CHECK_LAUNCH();
-            return ARFE_OK;
-        }
+    {
+        bool done;
+        int32_t rc = gemm_try_slabs(M, N, K, kb, batch, la, lb, e, st, slabs, slab_floats, &done);
+        if (rc || done) return rc;
     }
+    int splitk = (e.relu || e.accumulate) ? 1 : pick_splitk(M, N, batch, ksteps);
     if (splitk > 1) {
         if (hipMemsetAsync(e.c, 0, sizeof(float) * zero_elems, st) != hipSuccess) {
             set_error("gemm: memset failed");
@@ -480,8 +494,21 @@ using namespace arfe;
 // =========================================================================================================
 // nn.Linear
 // =========================================================================================================
+extern "C" int64_t arfe_linear_workspace_bytes(int32_t R, int32_t in_f, int32_t out_f) {
+    // up to 16 K-slices of the larger of the two activation-sized results (y [R,out], dx [R,in]) or of dw [out,in] when that
+    // is small; capped: a call whose plan needs more falls back to atomic partial sums
+    if (R < 0 || in_f <= 0 || out_f <= 0) return -1;
+    int64_t m = (int64_t)R * (in_f > out_f ? in_f : out_f);
+    const int64_t dw = (int64_t)in_f * out_f;
+    if (dw <= ((int64_t)4 << 20) && dw > m) m = dw;
+    int64_t bytes = 16 * m * (int64_t)sizeof(float);
+    const int64_t cap = (int64_t)256 << 20;
+    return (bytes < cap ? bytes : cap) + 64;
+}
+
 extern "C" int32_t arfe_linear_fwd(int32_t R, int32_t in_f, int32_t out_f, const float* x, const float* w,
-                                   const float* b, int32_t relu, float* y, void* stream) {
+                                   const float* b, int32_t relu, float* y, void* workspace, int64_t workspace_bytes,
+                                   void* stream) {
     ARFE_CHECK_ARG(R >= 0 && in_f > 0 && out_f > 0, ARFE_ERR_ARG, "linear_fwd: bad shape R=%d in=%d out=%d", R, in_f, out_f);
     if (R == 0) return ARFE_OK;
     ARFE_CHECK_ARG(x && w && y, ARFE_ERR_ARG, "linear_fwd: null pointer");
@@ -493,6 +520,13 @@ extern "C" int32_t arfe_linear_fwd(int32_t R, int32_t in_f, int32_t out_f, const
     int splitk = pick_splitk(R, out_f, 1, ksteps);
     EpiPlain e = epi_plain(y, 0, out_f);
     e.bias_n = b;
+    if (workspace) {                 // split-K through per-slice slabs: bias + ReLU ride in the reduction, no memset
+        EpiPlain fin = e;
+        fin.relu = relu;
+        bool done;
+        int32_t rc = gemm_try_slabs(R, out_f, in_f, 1, 1, la, lb, fin, st, (float*)workspace, workspace_bytes / (int64_t)sizeof(float), &done);
+        if (rc || done) return rc;
+    }
     if (splitk > 1) {
         // split-K: atomic partial sums into a zeroed output, activation in a second tiny pass
         if (hipMemsetAsync(y, 0, sizeof(float) * (size_t)R * out_f, st) != hipSuccess) {
@@ -515,12 +549,23 @@ extern "C" int32_t arfe_linear_fwd(int32_t R, int32_t in_f, int32_t out_f, const
 
 extern "C" int32_t arfe_linear_bwd(int32_t R, int32_t in_f, int32_t out_f, const float* x, const float* w,
                                    const float* dy, float* dx, int32_t accumulate_dx, int32_t mask_dx_by_x, float* dw,
-                                   float* db, void* stream) {
+                                   float* db, void* workspace, int64_t workspace_bytes, void* stream) {
     ARFE_CHECK_ARG(R >= 0 && in_f > 0 && out_f > 0, ARFE_ERR_ARG, "linear_bwd: bad shape");
     hipStream_t st = as_stream(stream);
+    float* slabs = (float*)workspace;
+    const int64_t slab_floats = workspace ? workspace_bytes / (int64_t)sizeof(float) : 0;
+    bool dw_by_slabs = false;
+    if (R > 0 && dw && slabs && x && dy) {
+        // dw[out,in] = dy^T . x through slabs when the planner splits K and the scratch holds the slices (no pre-zeroed dw)
+        LoadRowMajorI la{dy, 0, 0, out_f, out_f, R};
+        LoadRowMajorI lb{x, 0, 0, in_f, in_f, R};
+        EpiPlain e = epi_plain(dw, 0, in_f);
+        int32_t rcw = gemm_try_slabs(out_f, in_f, R, 1, 1, la, lb, e, st, slabs, slab_floats, &dw_by_slabs);
+        if (rcw) return rcw;
+    }
     {
         ZeroList z;
-        z.add(dw, (int64_t)out_f * in_f);
+        if (!dw_by_slabs) z.add(dw, (int64_t)out_f * in_f);
         z.add(db, out_f);
         int32_t zr = zero_buffers(z, st);
         if (zr) return zr;
@@ -528,7 +573,17 @@ extern "C" int32_t arfe_linear_bwd(int32_t R, int32_t in_f, int32_t out_f, const
     if (R == 0) return ARFE_OK;
     ARFE_CHECK_ARG(x && w && dy, ARFE_ERR_ARG, "linear_bwd: null pointer");
     int32_t rc;
-    if (dx) {
+    bool dx_done = false;
+    if (dx && slabs) {
+        LoadRowMajorK la{dy, 0, 0, out_f, R, out_f};
+        LoadRowMajorI lb{w, 0, 0, in_f, in_f, out_f};
+        EpiPlain e = epi_plain(dx, 0, in_f);
+        e.accumulate = accumulate_dx;
+        if (mask_dx_by_x) e.mask = x;
+        rc = gemm_try_slabs(R, in_f, out_f, 1, 1, la, lb, e, st, slabs, slab_floats, &dx_done);
+        if (rc) return rc;
+    }
+    if (dx && !dx_done) {
         // dx[R,in] = dy[R,out] . w[out,in] : A = dy (k=out contiguous), B(n=in,k=out) = w[k*in + n]
         LoadRowMajorK la{dy, 0, 0, out_f, R, out_f};
         LoadRowMajorI lb{w, 0, 0, in_f, in_f, out_f};
@@ -551,7 +606,7 @@ extern "C" int32_t arfe_linear_bwd(int32_t R, int32_t in_f, int32_t out_f, const
             ARFE_CHECK_LAUNCH();
         }
     }
-    if (dw) {
+    if (dw && !dw_by_slabs) {
         // dw[out,in] = dy^T[out,R] . x[R,in] : A(m=out,k=r) = dy[k*out + m] (m contiguous), B(n=in,k=r) = x[k*in+n]
         LoadRowMajorI la{dy, 0, 0, out_f, out_f, R};
         LoadRowMajorI lb{x, 0, 0, in_f, in_f, R};

@@ -461,10 +461,16 @@ def conv3x3_bwd_weight_op(x_view, x_roi_stride, R, C, w, dy, ws):
     return dw, db
 
 
+def _linear_ws(R, in_f, out_f, device):
+    """split-K scratch of the linear ops (per-slice partial sums, reduced in a fixed order instead of atomics)."""
+    return _ws(hip.lib().arfe_linear_workspace_bytes(R, in_f, out_f), device)
+
+
 def linear_fwd_op(x, w, b, relu):
     R, out_f, in_f = x.shape[0], w.shape[0], w.shape[1]
     y = torch.empty(R, out_f, device=x.device)
-    check(hip.lib().arfe_linear_fwd(R, in_f, out_f, ptr(x), ptr(w), ptr(b), int(relu), ptr(y), stream()),
+    ws = _linear_ws(R, in_f, out_f, x.device)
+    check(hip.lib().arfe_linear_fwd(R, in_f, out_f, ptr(x), ptr(w), ptr(b), int(relu), ptr(y), ptr(ws), ws.numel(), stream()),
           "arfe_linear_fwd")
     return y
 
@@ -474,8 +480,9 @@ def linear_bwd_data_op(x, w, dy, dx=None, accumulate_dx=False, mask_dx_by_x=Fals
     R, out_f, in_f = x.shape[0], w.shape[0], w.shape[1]
     if dx is None:
         dx = torch.empty(R, in_f, device=x.device)
+    ws = _linear_ws(R, in_f, out_f, x.device)
     check(hip.lib().arfe_linear_bwd(R, in_f, out_f, ptr(x), ptr(w), ptr(dy), ptr(dx), int(accumulate_dx),
-                                    int(mask_dx_by_x), 0, 0, stream()), "arfe_linear_bwd")
+                                    int(mask_dx_by_x), 0, 0, ptr(ws), ws.numel(), stream()), "arfe_linear_bwd")
     return dx
 
 
@@ -483,8 +490,9 @@ def linear_bwd_weight_op(x, w, dy):
     R, out_f, in_f = x.shape[0], w.shape[0], w.shape[1]
     dw = torch.empty_like(w)
     db = torch.empty(out_f, device=x.device)
-    check(hip.lib().arfe_linear_bwd(R, in_f, out_f, ptr(x), ptr(w), ptr(dy), 0, 0, 0, ptr(dw), ptr(db), stream()),
-          "arfe_linear_bwd")
+    ws = _linear_ws(R, in_f, out_f, x.device)
+    check(hip.lib().arfe_linear_bwd(R, in_f, out_f, ptr(x), ptr(w), ptr(dy), 0, 0, 0, ptr(dw), ptr(db), ptr(ws), ws.numel(),
+                                    stream()), "arfe_linear_bwd")
     return dw, db
 
 

@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ARFE_LIB", os.path.join(_HERE, "libarfe_hip.so"))   # ARFE_LIB: development builds only
 MAX_LEVELS = 8
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_f32p = ctypes.c_void_p
 _i32, _i64, _vp, _f32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_float
@@ -69,8 +69,9 @@ SIGNATURES = {
     "arfe_conv3x3_bwd_weight": (_i32, [_i32, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
     "arfe_rff_fuse_fwd": (_i32, [_i32, _i32, _vp, _i64, _vp, _vp, _vp, _vp]),
     "arfe_rff_fuse_bwd": (_i32, [_i32, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
-    "arfe_linear_fwd": (_i32, [_i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _vp]),
-    "arfe_linear_bwd": (_i32, [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
+    "arfe_linear_workspace_bytes": (_i64, [_i32, _i32, _i32]),
+    "arfe_linear_fwd": (_i32, [_i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _i64, _vp]),
+    "arfe_linear_bwd": (_i32, [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i64, _vp]),
     "arfe_conv1x1_fwd": (_i32, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "arfe_conv1x1_bwd_data": (_i32, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "arfe_conv1x1_bwd_weight": (_i32, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define ARFE_ABI_VERSION 1
+#define ARFE_ABI_VERSION 2   /* 2: arfe_linear_fwd / _bwd take an optional split-K scratch (workspace, workspace_bytes) */
 #define ARFE_MAX_LEVELS 8
 
 #define ARFE_OK 0
@@ -213,15 +213,19 @@ int32_t arfe_rff_fuse_bwd(int32_t R, int32_t C, const float* ori, int64_t ori_ro
                           float* dlw, float* dlh, void* stream);
 
 /* nn.Linear (shared_fcs / fc_cls / fc_reg, multirois_bbox_head.py:203-235): y = act(x W^T + b),
- * x [R,in], W [out,in], y [R,out]. */
+ * x [R,in], W [out,in], y [R,out].
+ * workspace (optional, may be NULL / 0 bytes): scratch of arfe_linear_workspace_bytes(R, in, out) bytes.  With it a
+ * contraction whose plan cuts K stores per-slice partial sums there and reduces them in a fixed order (bias, ReLU, mask and
+ * accumulate applied by the reduction); without it (or when it is too small) the slices add atomically into the output. */
+int64_t arfe_linear_workspace_bytes(int32_t R, int32_t in_f, int32_t out_f);
 int32_t arfe_linear_fwd(int32_t R, int32_t in_f, int32_t out_f, const float* x, const float* w, const float* b,
-                        int32_t relu, float* y, void* stream);
+                        int32_t relu, float* y, void* workspace, int64_t workspace_bytes, void* stream);
 /* dx = (dy W) (* [x > 0] when mask_dx_by_x: x is then the post-ReLU output of the previous layer, so the mask is
  * that layer's ReLU backward); written, or accumulated when accumulate_dx != 0; dx may be NULL.
  * dw = dy^T x, db = colsum(dy). */
 int32_t arfe_linear_bwd(int32_t R, int32_t in_f, int32_t out_f, const float* x, const float* w,
                         const float* dy, float* dx, int32_t accumulate_dx, int32_t mask_dx_by_x, float* dw,
-                        float* db, void* stream);
+                        float* db, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- base FPN: mmdet/models/necks/fpn.py:166-201 ----------------------------------------------
  * The lateral 1x1 convs (fpn.py:117-124,170-173), the top-down `laterals[i-1] += F.interpolate(laterals[i], size=...)`

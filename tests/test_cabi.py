@@ -51,7 +51,8 @@ def test_argument_errors_do_not_touch_the_gpu():
     assert l.arfe_fpn_gather_fwd(ctypes.byref(p), None, None, None, None) == -1
     assert b"num_levels" in l.arfe_last_error()
     assert l.arfe_map_roi_levels(4, None, 6, 56.0, None, None) == -1      # num_levels > 5
-    assert l.arfe_linear_fwd(-1, 4, 4, None, None, None, 0, None, None) == -1
+    assert l.arfe_linear_fwd(-1, 4, 4, None, None, None, 0, None, None, 0, None) == -1
+    assert l.arfe_linear_workspace_bytes(1024, 12544, 1024) == (256 << 20) + 64 and l.arfe_linear_workspace_bytes(-1, 4, 4) == -1
     assert l.arfe_conv3x3_packed_bytes(256) == 4 * 9 * 256 * 256 * 4      # fwd + dgrad layouts, as packed words and as bf16 planes
     assert l.arfe_conv3x3_workspace_bytes(256) == 32 * 9 * 256 * 256 * 4   # 32 row-slice slabs of the stage-once weight gradient
     assert l.arfe_conv3x3_workspace_bytes(20) == 9 * 20 * 20 * 4

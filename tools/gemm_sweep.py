@@ -18,7 +18,7 @@ if '--one' in sys.argv:
     for (R, i, o) in SHAPES:
         x = torch.randn(R, i, device=dev); w = torch.randn(o, i, device=dev) * 0.02; b = torch.zeros(o, device=dev)
         y = torch.empty(R, o, device=dev)
-        ms = timeit(lambda: check(L.arfe_linear_fwd(R, i, o, ptr(x), ptr(w), ptr(b), 0, ptr(y), stream()), 'lin'), iters=20)
+        ms = timeit(lambda: check(L.arfe_linear_fwd(R, i, o, ptr(x), ptr(w), ptr(b), 0, ptr(y), 0, 0, stream()), 'lin'), iters=20)
         print(f"{os.environ.get('ARFE_GEMM_PLAN', 'auto'):>5s}  R={R:5d} in={i:5d} out={o:4d}: {ms*1e3:8.1f} us", flush=True)
 else:
     for plan in ['auto', 'S1', 'S2', 'S4', 'S8', 'S16', 'S32', 'S64', 'L1', 'L2', 'L4', 'L8', 'L16', 'L32']:

@@ -36,7 +36,7 @@ def conv(R, C=256):
 def linear(R, i, o):
     x = torch.randn(R, i, device=dev); w = torch.randn(o, i, device=dev) * 0.02; b = torch.zeros(o, device=dev)
     y = torch.empty(R, o, device=dev)
-    ms = timeit(lambda: check(L.arfe_linear_fwd(R, i, o, ptr(x), ptr(w), ptr(b), 0, ptr(y), stream()), 'lin'))
+    ms = timeit(lambda: check(L.arfe_linear_fwd(R, i, o, ptr(x), ptr(w), ptr(b), 0, ptr(y), 0, 0, stream()), 'lin'))
     fl = 2.0 * R * i * o
     print(f"linear fwd R={R} in={i} out={o}: {ms*1e3:8.1f} us  {fl/ms/1e9:7.1f} TFLOP/s")
 
