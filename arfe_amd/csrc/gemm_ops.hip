@@ -384,7 +384,8 @@ __global__ __launch_bounds__(256) void gemm_slab_reduce_kernel(const float* __re
     const int n0 = q * 4;
     const int64_t o = z * e.sz + (int64_t)m * e.ld + n0;
     float s[4] = {0.f, 0.f, 0.f, 0.f};
-    const bool vec = n0 + 3 < N && ((o | stride) & 3) == 0 && (((uintptr_t)slabs) & 15) == 0;
+    const bool vec = n0 + 3 < N;          // float4_u promises 4-byte alignment only: rows of any width take the 16-byte read
+#pragma unroll 4
     for (int k = 0; k < nslabs; ++k) {
         const float* p = slabs + (int64_t)k * stride + o;
         if (vec) {

@@ -527,11 +527,13 @@ def _rff_head_forward(x, params, packs):
     z2 = conv3x3_fwd_op(z.data_ptr(), C * 49, R, C, pk_f, b_f, True)
     f1 = linear_fwd_op(z2.view(R, C * 49), w1, b1, True)
     f2 = linear_fwd_op(f1, w2, b2, True)
-    # the two predictors are small, latency-bound and independent: side by side
-    reg = on_side(x.device, lambda: linear_fwd_op(f2, wr, br, False))
-    cls = linear_fwd_op(f2, wc, bc, False)
-    join_side(x.device)
-    return cls, reg, (x, w_wh, w_hh, w_f, w1, w2, wc, wr, lw, lh, z, z2, f1, f2, pk_wh, pk_hh, pk_f)
+    # the two predictors are small and latency-bound: ONE contraction over the stacked weights [classes + 4*classes, fc],
+    # cls / reg are the column blocks of its output (the backward stacks the two incoming gradients the same way)
+    wcr, bcr = torch.cat([wc, wr], 0), torch.cat([bc, br], 0)
+    ycr = linear_fwd_op(f2, wcr, bcr, False)
+    nc = wc.shape[0]
+    cls, reg = ycr[:, :nc], ycr[:, nc:]
+    return cls, reg, (x, w_wh, w_hh, w_f, w1, w2, wcr, bc, lw, lh, z, z2, f1, f2, pk_wh, pk_hh, pk_f)
 
 
 def _rff_head_backward(saved, dcls, dreg, join=True, defer_gate_wgrads=False):
@@ -542,23 +544,27 @@ def _rff_head_backward(saved, dcls, dreg, join=True, defer_gate_wgrads=False):
     critical chain on the current stream; each parameter gradient is launched on the side stream as soon as its incoming
     gradient exists.  join=False leaves the side stream (the three conv weight gradients, 0.65 ms of matrix-pipe work
     nothing downstream reads) running: the caller joins after it has enqueued more data-path work."""
-    x, w_wh, w_hh, w_f, w1, w2, wc, wr, lw, lh, z, z2, f1, f2, pk_wh, pk_hh, pk_f = saved
+    x, w_wh, w_hh, w_f, w1, w2, wcr, bc, lw, lh, z, z2, f1, f2, pk_wh, pk_hh, pk_f = saved
+    nc = bc.shape[0]                  # the stacked predictor weights split after the classifier's rows
     R, C3 = x.shape[0], x.shape[1]
     C = C3 // 3
     dev = x.device
     rs = C3 * 49
-    dcls = dcls.contiguous() if dcls is not None else torch.zeros(R, wc.shape[0], device=dev)
-    dreg = dreg.contiguous() if dreg is not None else torch.zeros(R, wr.shape[0], device=dev)
+    dycr = torch.empty(R, wcr.shape[0], device=dev)
+    for blk, g in ((dycr[:, :nc], dcls), (dycr[:, nc:], dreg)):
+        if g is None:
+            blk.zero_()
+        else:
+            blk.copy_(g)
     ws = _ws(hip.lib().arfe_conv3x3_workspace_bytes(C), dev)
     z2f = z2.view(R, C * 49)
 
     def side_do(fn):
         return on_side(dev, fn)
 
-    dwc, dbc = side_do(lambda: linear_bwd_weight_op(f2, wc, dcls))
-    dwr, dbr = side_do(lambda: linear_bwd_weight_op(f2, wr, dreg))
-    df2 = linear_bwd_data_op(f2, wc, dcls)
-    linear_bwd_data_op(f2, wr, dreg, dx=df2, accumulate_dx=True, mask_dx_by_x=True)        # df2 *= [f2>0]
+    dwcr, dbcr = side_do(lambda: linear_bwd_weight_op(f2, wcr, dycr))
+    dwc, dbc, dwr, dbr = dwcr[:nc], dbcr[:nc], dwcr[nc:], dbcr[nc:]
+    df2 = linear_bwd_data_op(f2, wcr, dycr, mask_dx_by_x=True)                             # df2 *= [f2>0]
     dw2, db2 = side_do(lambda: linear_bwd_weight_op(f1, w2, df2))
     df1 = linear_bwd_data_op(f1, w2, df2, mask_dx_by_x=True)                               # df1 *= [f1>0]
     dw1, db1 = side_do(lambda: linear_bwd_weight_op(z2f, w1, df1))
