@@ -230,7 +230,11 @@ __device__ __forceinline__ float axis_weight(float start, float bin, int grid, i
 // Per-RoI 1-D bilinear weight tables (one small workgroup per RoI, all sets): for the RoI's first RW_EXT feature
 // rows / columns, w[axis][bin][i] = sum over the bin's grid samples of the tap weight on feature index origin+i.
 // The tile kernel then only copies its 16-row / 16-column slice instead of re-deriving the geometry per tile.
-constexpr int RW_EXT = 64;
+constexpr int RW_EXT = 160;    // table entries per (axis, bin): windows up to 159 rows / columns (was 64: 5 % of the bench's RoIs -
+                               // thin long boxes on the finest level, windows up to 135 - fell to the per-sample forms below and
+                               // made the tail of both kernels: 349 -> 281 us forward, 487 -> 426 us backward without them)
+constexpr int RW_SLACK = 16;   // entries past a window's extent that are still written (zeros): a 16-row tile or an 8-row read
+                               // group that overlaps the window's end reads that far
 // big: 0 table valid, 1 window larger than the table (consumers compute on the fly), 2 no sample inside the map
 
 __global__ __launch_bounds__(256) void roi_weight_table_kernel(RoiLevels L, RoiSets S, int P, int sample_num,
@@ -257,9 +261,13 @@ __global__ __launch_bounds__(256) void roi_weight_table_kernel(RoiLevels L, RoiS
     }
     if (big) return;
     float* wt = wtab + (int64_t)slot * 2 * 7 * RW_EXT;
+    // only the window's extent (+ slack) is evaluated and written: nothing reads past it
+    const int ny = y1 - y0 + 1 + RW_SLACK < RW_EXT ? y1 - y0 + 1 + RW_SLACK : RW_EXT;
+    const int nxw = x1 - x0 + 1 + RW_SLACK < RW_EXT ? x1 - x0 + 1 + RW_SLACK : RW_EXT;
     for (int i = threadIdx.x; i < 2 * 7 * RW_EXT; i += 256) {
         const int axis = i / (7 * RW_EXT), rem = i - axis * 7 * RW_EXT;
         const int pb = rem / RW_EXT, off = rem - pb * RW_EXT;
+        if (off >= (axis == 0 ? ny : nxw)) continue;
         float w = axis == 0 ? axis_weight(g.y_start, g.bin_h, g.grid_h, pb, H, y0 + off)
                             : axis_weight(g.x_start, g.bin_w, g.grid_w, pb, W, x0 + off);
         if ((axis == 0 ? y0 : x0) + off >= (axis == 0 ? H : W)) w = 0.f;
@@ -272,7 +280,7 @@ __global__ __launch_bounds__(256) void roi_weight_table_kernel(RoiLevels L, RoiS
         const int axis = threadIdx.x / 7, pb = threadIdx.x - axis * 7;
         int lo = 0, hi = 0;
         bool any = false;
-        for (int i = 0; i < RW_EXT; ++i)
+        for (int i = 0; i < (axis == 0 ? ny : nxw); ++i)
             if (w_s[axis][pb][i] != 0.f) { if (!any) { lo = i; any = true; } hi = i + 1; }
         if (axis == 0) { h->ylo[pb] = lo; h->yhi[pb] = hi; } else { h->xlo[pb] = lo; h->xhi[pb] = hi; }
         w_s[axis][pb][0] = (float)hi;  // reuse as scratch for the extents (column 0 is consumed above)
@@ -339,7 +347,7 @@ __global__ __launch_bounds__(256) void roialign_fwd_sep_kernel(RoiLevels L, RoiS
                                                                float* __restrict__ out, int64_t out_roi_stride) {
     __shared__ __attribute__((aligned(16))) float wyT_s[RW_EXT][8];   // [window row][bin], pre-scaled by 1/samples
     __shared__ float wx_s[7][RW_EXT];
-    __shared__ float U_s[4][7][RW_EXT];
+    __shared__ float U_s[4][7][64];                                    // one 64-column chunk of a wave's row sums
     __shared__ RoiWeightHdr h_s;
     // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2): the channel slice is the fast index, so
     // with 8 slices an XCD only ever sees its own 32 channels of the pyramid, and the RoIs come in spatial order.
@@ -393,12 +401,15 @@ __global__ __launch_bounds__(256) void roialign_fwd_sep_kernel(RoiLevels L, RoiS
     if (tid < (int)(sizeof(RoiWeightHdr) / sizeof(int))) ((int*)&h_s)[tid] = ((const int*)hp)[tid];
     const float* wt = wtab + (int64_t)slot * 2 * 7 * RW_EXT;
     const float inv = hp->inv;
-    for (int i = tid; i < 7 * RW_EXT; i += 256) {
-        const int pb = i / RW_EXT, off = i - pb * RW_EXT;
-        wyT_s[off][pb] = wt[i] * inv;
-        (&wx_s[0][0])[i] = wt[7 * RW_EXT + i];
+    {
+        const int hn = hp->hext + 8 < RW_EXT ? hp->hext + 8 : RW_EXT, wn = hp->wext < RW_EXT ? hp->wext : RW_EXT;
+        for (int i = tid; i < 7 * RW_EXT; i += 256) {
+            const int pb = i / RW_EXT, off = i - pb * RW_EXT;
+            if (off < hn) wyT_s[off][pb] = wt[i] * inv;
+            if (off < wn) (&wx_s[0][0])[i] = wt[7 * RW_EXT + i];
+        }
+        if (tid < hn) wyT_s[tid][7] = 0.f;
     }
-    if (tid < RW_EXT) wyT_s[tid][7] = 0.f;
     __syncthreads();
     const int wext = h_s.wext, hext = h_s.hext;
     // A lane is one window column; narrow windows put 4 (<= 16 columns) or 2 (<= 32) channels on one wave, so that a
@@ -411,6 +422,43 @@ __global__ __launch_bounds__(256) void roialign_fwd_sep_kernel(RoiLevels L, RoiS
     const int colc = col < wext ? col : wext - 1;          // lanes past the window re-read its last column (unused)
     const int q = lane < 49 ? lane : 48, qph = q / 7, qpw = q - qph * 7;
     const int xlo = h_s.xlo[qpw], xhi = h_s.xhi[qpw];
+    if (wext > 64) {
+        // windows wider than a wave (5 % of the bench's RoIs: thin long boxes): 64 columns at a time, one channel per wave,
+        // the column contraction adds up over the chunks.  Kept apart from the loop below so that its registers stay few.
+        const int nchunk = (wext + 63) >> 6;
+        for (int cb = wave; cb < ncc; cb += 4) {
+            float wide_sum = 0.f;
+            for (int ch = 0; ch < nchunk; ++ch) {
+                const int colk = ch * 64 + lane < wext ? ch * 64 + lane : wext - 1;
+                const float* f = feat + (((int64_t)bimg * L.C + c0 + cb) * H + h_s.y0) * W + h_s.x0 + colk;
+                float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                for (int y = 0; y < hext; y += 4) {
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = f[(int64_t)(y + j < hext ? y + j : hext - 1) * W];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float4_u wa = *reinterpret_cast<const float4_u*>(&wyT_s[y + j][0]);
+                        const float4_u wb = *reinterpret_cast<const float4_u*>(&wyT_s[y + j][4]);
+                        acc[0] += wa[0] * v[j]; acc[1] += wa[1] * v[j]; acc[2] += wa[2] * v[j]; acc[3] += wa[3] * v[j];
+                        acc[4] += wb[0] * v[j]; acc[5] += wb[1] * v[j]; acc[6] += wb[2] * v[j];
+                    }
+                }
+#pragma unroll
+                for (int ph = 0; ph < 7; ++ph) U_s[wave][ph][lane] = acc[ph];
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+                if (lane < 49) {
+                    const int xa = xlo > ch * 64 ? xlo : ch * 64, xb = xhi < ch * 64 + 64 ? xhi : ch * 64 + 64;
+                    for (int x = xa; x < xb; ++x) wide_sum += U_s[wave][qph][x - ch * 64] * wx_s[qpw][x];
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);     // the row sums are read before the next chunk overwrites them
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (lane < 49) obase[cb * 49 + lane] = wide_sum;
+        }
+        return;
+    }
     for (int cb = wave * pack; cb < ncc; cb += 4 * pack) {
         const int c = cb + half;
         const float* f = feat + (((int64_t)bimg * L.C + c0 + (c < ncc ? c : cb)) * H + h_s.y0) * W + h_s.x0 + colc;
@@ -419,7 +467,7 @@ __global__ __launch_bounds__(256) void roialign_fwd_sep_kernel(RoiLevels L, RoiS
             float v[RF_ROWS];
 #pragma unroll
             for (int j = 0; j < RF_ROWS; ++j) v[j] = f[(int64_t)(y + j < hext ? y + j : hext - 1) * W];
-            // rows past the window (y + j >= hext, still < RW_EXT) carry zero weight in the table: no branch per row
+            // rows past the window (y + j >= hext) carry zero weight in the table: no branch per row
 #pragma unroll
             for (int j = 0; j < RF_ROWS; ++j) {
                 const float4_u wa = *reinterpret_cast<const float4_u*>(&wyT_s[y + j][0]);
