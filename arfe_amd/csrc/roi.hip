@@ -935,34 +935,70 @@ extern "C" int32_t arfe_roialign_bwd_prepare(const arfe_pyramid_t* pyr, const in
     return ARFE_OK;
 }
 
+namespace {
+// shared argument checks / tables of the two halves of the prepared backward
+int32_t roi_bwd_args(const arfe_pyramid_t* pyr, float* const* dfeats, const int32_t* strides, int nsets, int R,
+                     const float* const* rois, const int64_t* const* levels, int pooled, int sample_num, const void* workspace,
+                     RoiLevels& L, RoiSets& S) {
+    int32_t rc = check_pyramid(pyr);
+    if (rc) return rc;
+    ARFE_CHECK_ARG(R >= 0 && nsets >= 1 && nsets <= RB_MAXSETS && sample_num >= 0, ARFE_ERR_ARG, "roialign_bwd: bad arguments");
+    ARFE_CHECK_ARG(pooled == 7, ARFE_ERR_ARG, "roialign_bwd: only 7x7 pooling has a kernel (got %d)", pooled);
+    ARFE_CHECK_ARG(dfeats && strides && workspace && (R == 0 || (rois && levels)), ARFE_ERR_ARG, "roialign_bwd: null pointer");
+    ARFE_CHECK_ARG(fill_roi_levels(L, pyr, nullptr, dfeats, strides) == ARFE_OK, ARFE_ERR_ARG, "roialign_bwd: bad level table");
+    return fill_roi_sets(S, nsets, R, rois, levels, "roialign_bwd");
+}
+}  // namespace
+
+// First half of the prepared backward: zero the tiles of dfeats that the second half sums with atomics (those whose RoI list
+// is cut into slices).  Needs only the prepared workspace, so a caller that allocates dfeats early runs it off the critical
+// path; arfe_roialign_bwd_prepared = _prezero + _apply.
+extern "C" int32_t arfe_roialign_bwd_prezero(const arfe_pyramid_t* pyr, float* const* dfeats, const int32_t* strides,
+                                             int32_t nsets, int32_t R, const void* workspace, void* stream) {
+    int32_t rc = check_pyramid(pyr);
+    if (rc) return rc;
+    ARFE_CHECK_ARG(R >= 0 && nsets >= 1 && nsets <= RB_MAXSETS, ARFE_ERR_ARG, "roialign_bwd: bad arguments");
+    ARFE_CHECK_ARG(dfeats && strides && workspace, ARFE_ERR_ARG, "roialign_bwd: null pointer");
+    RoiLevels L;
+    ARFE_CHECK_ARG(fill_roi_levels(L, pyr, nullptr, dfeats, strides) == ARFE_OK, ARFE_ERR_ARG, "roialign_bwd: bad level table");
+    RoiBwdPlan p = plan_roi_bwd(pyr, nsets, R, const_cast<void*>(workspace));
+    const int nchunks = cdiv(L.C, RB_CC);
+    ARFE_CHECK_ARG((int64_t)p.ntiles * nchunks < (int64_t)1 << 31, ARFE_ERR_ARG, "roialign_bwd: pyramid too large");
+    hipLaunchKernelGGL(roi_zero_sliced_tiles_kernel, dim3(p.ntiles * nchunks), dim3(256), 0, as_stream(stream), L, p.T,
+                       (const int*)p.offsets, p.ntiles, nchunks);
+    ARFE_CHECK_LAUNCH();
+    return ARFE_OK;
+}
+
+extern "C" int32_t arfe_roialign_bwd_apply(const arfe_pyramid_t* pyr, float* const* dfeats, const int32_t* strides,
+                                           int32_t nsets, int32_t R, const float* const* rois, const int64_t* const* levels,
+                                           int32_t pooled, int32_t sample_num, const float* gout, int64_t gout_roi_stride,
+                                           const void* workspace, void* stream) {
+    RoiLevels L;
+    RoiSets S;
+    int32_t rc = roi_bwd_args(pyr, dfeats, strides, nsets, R, rois, levels, pooled, sample_num, workspace, L, S);
+    if (rc) return rc;
+    ARFE_CHECK_ARG(R == 0 || gout, ARFE_ERR_ARG, "roialign_bwd: null pointer");
+    RoiBwdPlan p = plan_roi_bwd(pyr, nsets, R, const_cast<void*>(workspace));
+    const int nchunks = cdiv(L.C, RB_CC);
+    ARFE_CHECK_ARG((int64_t)p.ntiles * nchunks < (int64_t)1 << 31, ARFE_ERR_ARG, "roialign_bwd: pyramid too large");
+    hipLaunchKernelGGL(roialign_bwd_tiles_kernel, dim3(p.ntiles * nchunks, 1, RB_SEGS), dim3(256), 0, as_stream(stream), L, S, p.T,
+                       pooled, sample_num, gout, gout_roi_stride, (const int*)p.offsets, (const int*)p.list, (const int*)p.lmeta,
+                       (const float*)p.wtab, p.ntiles, nchunks);
+    ARFE_CHECK_LAUNCH();
+    return ARFE_OK;
+}
+
 extern "C" int32_t arfe_roialign_bwd_prepared(const arfe_pyramid_t* pyr, float* const* dfeats, const int32_t* strides,
                                               int32_t nsets, int32_t R, const float* const* rois,
                                               const int64_t* const* levels, int32_t pooled, int32_t sample_num,
                                               const float* gout, int64_t gout_roi_stride, const void* workspace,
                                               void* stream) {
-    int32_t rc = check_pyramid(pyr);
+    ARFE_CHECK_ARG(R == 0 || gout, ARFE_ERR_ARG, "roialign_bwd: null pointer");
+    int32_t rc = arfe_roialign_bwd_prezero(pyr, dfeats, strides, nsets, R, workspace, stream);
     if (rc) return rc;
-    ARFE_CHECK_ARG(R >= 0 && nsets >= 1 && nsets <= RB_MAXSETS && sample_num >= 0, ARFE_ERR_ARG, "roialign_bwd: bad arguments");
-    ARFE_CHECK_ARG(pooled == 7, ARFE_ERR_ARG, "roialign_bwd: only 7x7 pooling has a kernel (got %d)", pooled);
-    ARFE_CHECK_ARG(dfeats && strides && workspace && (R == 0 || (rois && levels && gout)), ARFE_ERR_ARG,
-                   "roialign_bwd: null pointer");
-    RoiLevels L;
-    ARFE_CHECK_ARG(fill_roi_levels(L, pyr, nullptr, dfeats, strides) == ARFE_OK, ARFE_ERR_ARG, "roialign_bwd: bad level table");
-    RoiSets S;
-    rc = fill_roi_sets(S, nsets, R, rois, levels, "roialign_bwd");
-    if (rc) return rc;
-    RoiBwdPlan p = plan_roi_bwd(pyr, nsets, R, const_cast<void*>(workspace));
-    hipStream_t st = as_stream(stream);
-    const int nchunks = cdiv(L.C, RB_CC);
-    ARFE_CHECK_ARG((int64_t)p.ntiles * nchunks < (int64_t)1 << 31, ARFE_ERR_ARG, "roialign_bwd: pyramid too large");
-    hipLaunchKernelGGL(roi_zero_sliced_tiles_kernel, dim3(p.ntiles * nchunks), dim3(256), 0, st, L, p.T, (const int*)p.offsets,
-                       p.ntiles, nchunks);
-    ARFE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(roialign_bwd_tiles_kernel, dim3(p.ntiles * nchunks, 1, RB_SEGS), dim3(256), 0, st, L, S, p.T, pooled,
-                       sample_num, gout, gout_roi_stride, (const int*)p.offsets, (const int*)p.list, (const int*)p.lmeta,
-                       (const float*)p.wtab, p.ntiles, nchunks);
-    ARFE_CHECK_LAUNCH();
-    return ARFE_OK;
+    return arfe_roialign_bwd_apply(pyr, dfeats, strides, nsets, R, rois, levels, pooled, sample_num, gout, gout_roi_stride,
+                                   workspace, stream);
 }
 
 extern "C" int32_t arfe_roialign_bwd(const arfe_pyramid_t* pyr, float* const* dfeats, const int32_t* strides,

@@ -351,13 +351,34 @@ def roialign_bwd_prepare_op(feats, strides, roi_sets, level_sets, pooled=7, samp
     return ws
 
 
-def roialign_bwd_op(shapes, strides, roi_sets, level_sets, gout, pooled=7, sample_num=0, prepared=None):
-    """d(feats) of all RoI sets at once; every element is written by the kernel (no zero-fill, no atomics).
-    prepared: the workspace of roialign_bwd_prepare_op (already ordered before the current stream), or None."""
-    dev = gout.device
+def roialign_bwd_prezero_op(shapes, strides, roi_sets, prepared):
+    """Allocates d(feats) and zeroes the tiles the scatter sums with atomics (current stream; needs `prepared`, the workspace of
+    roialign_bwd_prepare_op, ordered before it).  -> dfeats for roialign_bwd_op(..., prezeroed=dfeats)."""
+    dev = prepared.device
     dfeats = [torch.empty(shape, device=dev) for shape in shapes]
     pyr = Pyramid.of(dfeats, 0)
     nsets, R = len(roi_sets), roi_sets[0].shape[0]
+    check(hip.lib().arfe_roialign_bwd_prezero(ctypes.byref(pyr), ptr_array(dfeats), _stride_array(strides), nsets, R,
+                                              ptr(prepared), stream()), "arfe_roialign_bwd_prezero")
+    return dfeats
+
+
+def roialign_bwd_op(shapes, strides, roi_sets, level_sets, gout, pooled=7, sample_num=0, prepared=None, prezeroed=None):
+    """d(feats) of all RoI sets at once; every element is written by the kernel (no zero-fill, no atomics).
+    prepared: the workspace of roialign_bwd_prepare_op (already ordered before the current stream), or None.
+    prezeroed: the dfeats of roialign_bwd_prezero_op (same prepared workspace, ordered before the current stream)."""
+    dev = gout.device
+    nsets, R = len(roi_sets), roi_sets[0].shape[0]
+    if prezeroed is not None:
+        dfeats = list(prezeroed)
+        pyr = Pyramid.of(dfeats, 0)
+        with probe('roialign_bwd'):
+            check(hip.lib().arfe_roialign_bwd_apply(ctypes.byref(pyr), ptr_array(dfeats), _stride_array(strides), nsets, R,
+                                                    ptr_array(roi_sets), ptr_array(level_sets), pooled, sample_num, ptr(gout),
+                                                    gout.stride(0), ptr(prepared), stream()), "arfe_roialign_bwd_apply")
+        return dfeats
+    dfeats = [torch.empty(shape, device=dev) for shape in shapes]
+    pyr = Pyramid.of(dfeats, 0)
     with probe('roialign_bwd'):
         if prepared is None:
             ws = _ws(hip.lib().arfe_roialign_bwd_workspace_bytes(ctypes.byref(pyr), nsets, R), dev)
@@ -654,7 +675,14 @@ class RFFExtractHeadFunction(torch.autograd.Function):
         prepared, ctx.prep_event = None, None
         if R > 0:
             if any(ctx.needs_input_grad[4:4 + nfeat]):
-                prepared = on_side(dev, lambda: roialign_bwd_prepare_op(feats, strides, roi_sets, levels, pooled, sample_num))
+                shapes = [f.shape for f in feats]
+
+                def prep():
+                    ws = roialign_bwd_prepare_op(feats, strides, roi_sets, levels, pooled, sample_num)
+                    # d(feats) exists from here on (183 MB at the bench size for the length of the step): the few tiles the
+                    # backward sums with atomics are zeroed now, beside the forward, not in front of the backward kernel
+                    return ws, roialign_bwd_prezero_op(shapes, strides, roi_sets, ws)
+                prepared, ctx.dfeats = on_side(dev, prep)
                 ctx.prep_event = side_stream(dev).record_event()
             roialign_fwd_op(feats, strides, roi_sets, levels, x, pooled, sample_num)
         join_side(dev)                    # packs (and the prepare, long finished) before the first conv
@@ -683,7 +711,9 @@ class RFFExtractHeadFunction(torch.autograd.Function):
             if prepared is not None:
                 torch.cuda.current_stream().wait_event(ctx.prep_event)
             if roi_sets[0].shape[0] > 0:
-                dfeats = roialign_bwd_op(ctx.shapes, strides, roi_sets, levels, dx, pooled, sample_num, prepared)
+                pz = getattr(ctx, 'dfeats', None) if prepared is not None else None
+                ctx.dfeats = None             # a second backward (retain_graph) must not scatter into tensors already handed out
+                dfeats = roialign_bwd_op(ctx.shapes, strides, roi_sets, levels, dx, pooled, sample_num, prepared, prezeroed=pz)
             else:
                 dfeats = [torch.zeros(shape, device=dev) for shape in ctx.shapes]
         join_side(dev)                        # the parameter gradients

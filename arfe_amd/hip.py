@@ -61,6 +61,8 @@ SIGNATURES = {
     "arfe_roialign_bwd": (_i32, [_PP, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp]),
     "arfe_roialign_bwd_prepare": (_i32, [_PP, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp]),
     "arfe_roialign_bwd_prepared": (_i32, [_PP, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp]),
+    "arfe_roialign_bwd_prezero": (_i32, [_PP, _vp, _vp, _i32, _i32, _vp, _vp]),
+    "arfe_roialign_bwd_apply": (_i32, [_PP, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp]),
     "arfe_conv3x3_packed_bytes": (_i64, [_i32]),
     "arfe_conv3x3_workspace_bytes": (_i64, [_i32]),
     "arfe_conv3x3_pack_weights": (_i32, [_i32, _vp, _vp, _vp]),

@@ -177,6 +177,15 @@ int32_t arfe_roialign_bwd_prepared(const arfe_pyramid_t* pyr, float* const* dfea
                                    int32_t R, const float* const* rois, const int64_t* const* levels, int32_t pooled,
                                    int32_t sample_num, const float* gout, int64_t gout_roi_stride,
                                    const void* workspace, void* stream);
+/* _prepared itself in two calls: _prezero zeroes the (few) tiles of dfeats that are summed with atomics and needs nothing but
+ * the prepared workspace - a caller that allocates dfeats at forward time runs it there, off the backward's critical path;
+ * _apply is the scatter itself (every other element of dfeats is stored exactly once).  _prepared == _prezero + _apply. */
+int32_t arfe_roialign_bwd_prezero(const arfe_pyramid_t* pyr, float* const* dfeats, const int32_t* strides, int32_t nsets,
+                                  int32_t R, const void* workspace, void* stream);
+int32_t arfe_roialign_bwd_apply(const arfe_pyramid_t* pyr, float* const* dfeats, const int32_t* strides, int32_t nsets,
+                                int32_t R, const float* const* rois, const int64_t* const* levels, int32_t pooled,
+                                int32_t sample_num, const float* gout, int64_t gout_roi_stride, const void* workspace,
+                                void* stream);
 
 /* 3x3 conv, padding 1, on RoI features [R, C, 7, 7] (MultiBBoxHead wh_conv/hh_conv/final_conv,
  * bbox_heads/multirois_bbox_head.py:50-78,172-173,183) as an implicit GEMM on the matrix cores.

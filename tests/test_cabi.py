@@ -20,7 +20,7 @@ def test_header_declares_the_hot_path_entry_points():
     syms = declared_symbols()
     for must in ("arfe_fpn_gather_fwd", "arfe_fpn_gatemap_fwd", "arfe_fpn_scatter_fwd", "arfe_fpn_scatter_bwd",
                  "arfe_fpn_input_bwd", "arfe_fpn_gate_wgrad", "arfe_nonlocal_fwd", "arfe_nonlocal_bwd",
-                 "arfe_rff_make_rois", "arfe_map_roi_levels", "arfe_roialign_fwd", "arfe_roialign_bwd",
+                 "arfe_rff_make_rois", "arfe_map_roi_levels", "arfe_roialign_fwd", "arfe_roialign_bwd", "arfe_roialign_bwd_prezero", "arfe_roialign_bwd_apply",
                  "arfe_conv3x3_fwd", "arfe_conv3x3_bwd_data", "arfe_conv3x3_bwd_weight", "arfe_rff_fuse_fwd",
                  "arfe_rff_fuse_bwd", "arfe_linear_fwd", "arfe_linear_bwd"):
         assert must in syms

@@ -265,6 +265,11 @@ def test_roialign_bwd_prepared_route_equals_single_call(Fn, O, dev):
     two = Fn.roialign_bwd_op(shapes, O.STRIDES, sets, lv, gout, prepared=ws)
     for a, b in zip(one, two):
         assert relerr(a, b) <= 1e-6         # the tile lists are filled through atomic cursors: summation order varies
+    # the same in three calls: the atomically summed tiles zeroed ahead of time into early-allocated gradients
+    pz = Fn.roialign_bwd_prezero_op(shapes, O.STRIDES, sets, ws)
+    three = Fn.roialign_bwd_op(shapes, O.STRIDES, sets, lv, gout, prepared=ws, prezeroed=pz)
+    for a, c in zip(one, three):
+        assert relerr(a, c) <= 1e-6
     fa = [f.clone().requires_grad_(True) for f in feats]
     fb = [f.clone().requires_grad_(True) for f in feats]
     ya = Fn.roi_extract(fa, sets, O.STRIDES)
