@@ -526,6 +526,11 @@ def rff_prepack(w_wh, w_hh, w_f):
     return on_side(ws[0].device, lambda: tuple(conv3x3_pack_op(w) for w in ws))
 
 
+def stack_predictors(wc, bc, wr, br):
+    """[fc_cls; fc_reg] as one weight / bias (the two predictors run as one contraction)."""
+    return torch.cat([wc, wr], 0), torch.cat([bc, br], 0)
+
+
 def _rff_head_forward(x, params, packs):
     """MultiBBoxHead.forward on contiguous fp32 tensors -> (cls, reg, saved tensors for _rff_head_backward).
     packs: (pk_wh, pk_hh, pk_f) already ordered before the current stream, or None (packed here)."""
@@ -533,8 +538,11 @@ def _rff_head_forward(x, params, packs):
     R, C3 = x.shape[0], x.shape[1]
     C = C3 // 3
     assert C3 == 3 * C and x.shape[2:] == (7, 7), "AR-RFF head expects [R, 3C, 7, 7]"
+    wcr = bcr = None
     if packs is None:
         pk_wh, pk_hh, pk_f = conv3x3_pack_op(w_wh), conv3x3_pack_op(w_hh), conv3x3_pack_op(w_f)
+    elif len(packs) == 5:
+        pk_wh, pk_hh, pk_f, wcr, bcr = packs
     else:
         pk_wh, pk_hh, pk_f = packs
     rs = C3 * 49
@@ -550,7 +558,8 @@ def _rff_head_forward(x, params, packs):
     f2 = linear_fwd_op(f1, w2, b2, True)
     # the two predictors are small and latency-bound: ONE contraction over the stacked weights [classes + 4*classes, fc],
     # cls / reg are the column blocks of its output (the backward stacks the two incoming gradients the same way)
-    wcr, bcr = torch.cat([wc, wr], 0), torch.cat([bc, br], 0)
+    if wcr is None:
+        wcr, bcr = stack_predictors(wc, bc, wr, br)
     ycr = linear_fwd_op(f2, wcr, bcr, False)
     nc = wc.shape[0]
     cls, reg = ycr[:, :nc], ycr[:, nc:]
@@ -571,12 +580,9 @@ def _rff_head_backward(saved, dcls, dreg, join=True, defer_gate_wgrads=False):
     C = C3 // 3
     dev = x.device
     rs = C3 * 49
-    dycr = torch.empty(R, wcr.shape[0], device=dev)
-    for blk, g in ((dycr[:, :nc], dcls), (dycr[:, nc:], dreg)):
-        if g is None:
-            blk.zero_()
-        else:
-            blk.copy_(g)
+    nr = wcr.shape[0] - nc
+    dycr = torch.cat([dcls if dcls is not None else torch.zeros(R, nc, device=dev),
+                      dreg if dreg is not None else torch.zeros(R, nr, device=dev)], 1)
     ws = _ws(hip.lib().arfe_conv3x3_workspace_bytes(C), dev)
     z2f = z2.view(R, C * 49)
 
@@ -670,7 +676,8 @@ class RFFExtractHeadFunction(torch.autograd.Function):
         dev = feats[0].device
         R, C = roi_sets[0].shape[0], feats[0].shape[1]
         ctx.set_materialize_grads(False)
-        packs = on_side(dev, lambda: tuple(conv3x3_pack_op(w) for w in (params[0], params[2], params[4])))
+        packs = on_side(dev, lambda: (*(conv3x3_pack_op(w) for w in (params[0], params[2], params[4])),
+                                      *stack_predictors(*params[10:14])))
         x = torch.empty(R, 3 * C, pooled, pooled, device=dev)
         prepared, ctx.prep_event = None, None
         if R > 0:
