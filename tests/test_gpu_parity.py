@@ -308,8 +308,12 @@ def test_roialign_realistic_geometry_matches_oracle(Fn, O, dev):
     C = 12
     feats_cpu = [torch.randn(2, C, h, w, generator=g) for h, w in O.PYRAMID_1333x800]
     rois = O.synth_rois(2, 160, seed=5)
+    # + the whole image, thin long boxes whose windows exceed a wave's 64 columns (table path in 64-column chunks, up to
+    # 159) or the 160-entry weight tables altogether (per-sample fallback), a tall one, a degenerate one
     rois = torch.cat([rois, torch.tensor([[0, 0., 0., 1343., 799.], [1, 2., 790., 1340., 799.],
-                                          [1, 1300., 0., 1343., 799.], [0, 640., 400., 640., 400.]])])
+                                          [1, 1300., 0., 1343., 799.], [0, 640., 400., 640., 400.],
+                                          [0, 100., 300., 800., 320.], [1, 40., 500., 1100., 530.],
+                                          [0, 10., 10., 30., 700.], [1, 600., 5., 1250., 12.]])])
     fo = [f.clone().requires_grad_(True) for f in feats_cpu]
     ref = O.roi_extract3(fo, rois)
     cot = torch.randn(ref.shape, generator=g)
@@ -322,6 +326,37 @@ def test_roialign_realistic_geometry_matches_oracle(Fn, O, dev):
     (got * cot.to(dev)).sum().backward()
     for i in range(5):
         assert relerr(fd[i].grad, fo[i].grad if fo[i].grad is not None else torch.zeros_like(fo[i])) <= TOL_GRAD, i
+
+
+@pytest.mark.parametrize("R,in_f,out_f", [(1024, 1024, 401), (96, 3136, 64), (200, 70, 33), (1024, 1024, 1024)])
+def test_linear_ops_with_and_without_splitk_scratch(Fn, dev, R, in_f, out_f):
+    """arfe_linear_fwd / _bwd (nn.Linear of the shared FCs and the stacked predictors): the slab split-K route (scratch
+    given: bias, ReLU, mask and accumulate are applied by the fixed-order reduce) and the scratch-less route (atomic partial
+    sums + separate activation pass) against an fp64 reference."""
+    import ctypes
+    from arfe_amd import hip
+    from arfe_amd.hip import ptr, stream, check
+    g = torch.Generator().manual_seed(R + in_f)
+    x = torch.randn(R, in_f, generator=g).relu().to(dev)           # post-ReLU activations: the mask is not trivial
+    w = (torch.randn(out_f, in_f, generator=g) * 0.05).to(dev)
+    b = torch.randn(out_f, generator=g).to(dev)
+    dy = torch.randn(R, out_f, generator=g).to(dev)
+    base = torch.randn(R, in_f, generator=g).to(dev)
+    xd, wd, bd, dyd = x.double(), w.double(), b.double(), dy.double()
+    y_ref = (xd @ wd.t() + bd).relu()
+    dx_ref = (base.double() + dyd @ wd) * (xd > 0)
+    dw_ref, db_ref = dyd.t() @ xd, dyd.sum(0)
+    L = hip.lib()
+    nbytes = L.arfe_linear_workspace_bytes(R, in_f, out_f)
+    for ws in (torch.empty(nbytes, dtype=torch.uint8, device=dev), None):
+        wp, wn = (ptr(ws), ws.numel()) if ws is not None else (0, 0)
+        y = torch.empty(R, out_f, device=dev)
+        check(L.arfe_linear_fwd(R, in_f, out_f, ptr(x), ptr(w), ptr(b), 1, ptr(y), wp, wn, stream()), "fwd")
+        assert relerr(y, y_ref.float()) <= TOL
+        dx = base.clone()
+        dw, db = torch.empty_like(w), torch.empty(out_f, device=dev)
+        check(L.arfe_linear_bwd(R, in_f, out_f, ptr(x), ptr(w), ptr(dy), ptr(dx), 1, 1, ptr(dw), ptr(db), wp, wn, stream()), "bwd")
+        assert relerr(dx, dx_ref.float()) <= TOL and relerr(dw, dw_ref.float()) <= TOL and relerr(db, db_ref.float()) <= TOL
 
 
 def test_rff_head_with_prepacked_weights_equals_plain_call(Fn, dev):
