@@ -498,15 +498,24 @@ __global__ __launch_bounds__(256) void roialign_fwd_sep_kernel(RoiLevels L, RoiS
 //   C:  T[(c,ph)][x] = sum_pw G[c][ph][pw] wx[pw][x]      D:  dX_c[y][x] += sum_ph wy[y][ph] T_c[ph][x]
 // (separable form of the bilinear scatter; every feature element is written once, no atomics unless a long list is cut).
 constexpr int RB_NB = 4;
-constexpr int RB_SEGS = 4;        // slices of a long RoI list
-constexpr int RB_SEG_MIN = 32;    // lists up to this length stay in one workgroup (plain stores)
+// Slicing a long RoI list over several workgroups (grid.z; the slices add atomically into pre-zeroed tiles) is OFF by default:
+// the lists of the bench (up to 201 RoIs on a coarse tile, dispatched first) finish inside the kernel's run anyway, while every
+// extra grid.z layer is 12 k workgroups that start only to exit - measured 434 us (32, 4) / 467 us (150, 2) / 391 us (off)
+// for the backward, the same ranking at 1000 RoIs per image.  ARFE_RB_SEG=<min list length>,<slices> switches it on.
+constexpr int RB_SEGS_DEF = 1;    // slices of a long RoI list
+constexpr int RB_SEG_MIN_DEF = 1 << 30;   // lists up to this length stay in one workgroup (plain stores)
+struct RbSeg { int segs, seg_min; };
+static RbSeg rb_seg() {
+    static const RbSeg v = []() { RbSeg r{RB_SEGS_DEF, RB_SEG_MIN_DEF}; const char* e = getenv("ARFE_RB_SEG"); if (e) sscanf(e, "%d,%d", &r.seg_min, &r.segs); return r; }();
+    return v;
+}
 constexpr int RB_GS = 60, RB_TS = 20;
 __device__ __forceinline__ int rb_wrow(int r) { return r * 8 + ((r >> 3) << 2); }   // start of weight row r (see the LDS note)
 // Only the tiles whose RoI list is cut into slices are summed with atomics and need a zeroed output: every other tile
 // (the empty ones included) is stored exactly once by the tile kernel.  Zeroing just those replaces a fill of the whole
 // pyramid gradient (183 MB per launch at the bench size).
 __global__ __launch_bounds__(256) void roi_zero_sliced_tiles_kernel(RoiLevels L, RoiTileTable T, const int* __restrict__ offsets,
-                                                                    int ntiles, int nchunks) {
+                                                                    int ntiles, int nchunks, int RB_SEG_MIN) {
     const int tile = (int)(blockIdx.x / (unsigned)nchunks);
     if (offsets[tile + 1] - offsets[tile] <= RB_SEG_MIN) return;
     int lvl = 0;
@@ -531,7 +540,7 @@ __global__ __launch_bounds__(256) void roialign_bwd_tiles_kernel(RoiLevels L, Ro
                                                                  const float* __restrict__ gout, int64_t g_roi_stride,
                                                                  const int* __restrict__ offsets, const int* __restrict__ list,
                                                                  const int* __restrict__ lmeta,
-                                                                 const float* __restrict__ wtab, int ntiles, int nchunks) {
+                                                                 const float* __restrict__ wtab, int ntiles, int nchunks, int RB_SEGS, int RB_SEG_MIN) {
     // LDS strides are chosen for the MFMA fragment accesses (64 banks x 4 B; PMC on the unpadded arrays: 56 % of the LDS
     // cycles were bank conflicts): a channel of G takes 60 floats (the two channels of an A fragment then sit 60, not 56,
     // floats apart), a T row 20 floats (the four 16-lane groups of a result store land 80 / 160 floats apart),
@@ -965,7 +974,7 @@ extern "C" int32_t arfe_roialign_bwd_prezero(const arfe_pyramid_t* pyr, float* c
     const int nchunks = cdiv(L.C, RB_CC);
     ARFE_CHECK_ARG((int64_t)p.ntiles * nchunks < (int64_t)1 << 31, ARFE_ERR_ARG, "roialign_bwd: pyramid too large");
     hipLaunchKernelGGL(roi_zero_sliced_tiles_kernel, dim3(p.ntiles * nchunks), dim3(256), 0, as_stream(stream), L, p.T,
-                       (const int*)p.offsets, p.ntiles, nchunks);
+                       (const int*)p.offsets, p.ntiles, nchunks, rb_seg().seg_min);
     ARFE_CHECK_LAUNCH();
     return ARFE_OK;
 }
@@ -982,9 +991,9 @@ extern "C" int32_t arfe_roialign_bwd_apply(const arfe_pyramid_t* pyr, float* con
     RoiBwdPlan p = plan_roi_bwd(pyr, nsets, R, const_cast<void*>(workspace));
     const int nchunks = cdiv(L.C, RB_CC);
     ARFE_CHECK_ARG((int64_t)p.ntiles * nchunks < (int64_t)1 << 31, ARFE_ERR_ARG, "roialign_bwd: pyramid too large");
-    hipLaunchKernelGGL(roialign_bwd_tiles_kernel, dim3(p.ntiles * nchunks, 1, RB_SEGS), dim3(256), 0, as_stream(stream), L, S, p.T,
+    hipLaunchKernelGGL(roialign_bwd_tiles_kernel, dim3(p.ntiles * nchunks, 1, rb_seg().segs), dim3(256), 0, as_stream(stream), L, S, p.T,
                        pooled, sample_num, gout, gout_roi_stride, (const int*)p.offsets, (const int*)p.list, (const int*)p.lmeta,
-                       (const float*)p.wtab, p.ntiles, nchunks);
+                       (const float*)p.wtab, p.ntiles, nchunks, rb_seg().segs, rb_seg().seg_min);
     ARFE_CHECK_LAUNCH();
     return ARFE_OK;
 }
