@@ -970,6 +970,7 @@ extern "C" int32_t arfe_roialign_bwd_prezero(const arfe_pyramid_t* pyr, float* c
     ARFE_CHECK_ARG(dfeats && strides && workspace, ARFE_ERR_ARG, "roialign_bwd: null pointer");
     RoiLevels L;
     ARFE_CHECK_ARG(fill_roi_levels(L, pyr, nullptr, dfeats, strides) == ARFE_OK, ARFE_ERR_ARG, "roialign_bwd: bad level table");
+    if (rb_seg().segs <= 1) return ARFE_OK;          // no list is sliced: every tile is stored exactly once, nothing to zero
     RoiBwdPlan p = plan_roi_bwd(pyr, nsets, R, const_cast<void*>(workspace));
     const int nchunks = cdiv(L.C, RB_CC);
     ARFE_CHECK_ARG((int64_t)p.ntiles * nchunks < (int64_t)1 << 31, ARFE_ERR_ARG, "roialign_bwd: pyramid too large");
