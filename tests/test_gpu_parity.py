@@ -556,7 +556,9 @@ def test_conv3x3_stage_once_kernel_matches_torch_cpu(Fn, dev, R, C):
     y = Fn.conv3x3_fwd_op(xd.data_ptr() + 4 * C * 49, 3 * C * 49, R, C, pk, bd, True)
     assert relerr(y, y_ref.detach()) <= TOL
     # data gradient of the un-activated conv (ReLU backward is the producer's job): dx = conv^T(dy * [y > 0])
-    dym = dyd * (y > 0)
+    # (the REFERENCE's activation mask: an output within rounding of zero may flip sign between the two - one such element
+    # in 1 M with ARFE_GEMM_F32=1 at (64, 320) - and a flipped mask element is a 3 % error in max-norm, not a kernel error)
+    dym = dyd * (y_ref.detach() > 0).to(dev)
     dx = torch.full_like(xd, float('nan'))
     Fn.conv3x3_bwd_data_op(R, C, pk, dym.contiguous(), dx.data_ptr() + 4 * C * 49, 3 * C * 49)
     assert relerr(dx[:, C:2 * C], xs.grad) <= TOL_GRAD
@@ -684,7 +686,7 @@ def test_neck_sequence_fpn_then_arfpn_matches_oracle(O, dev):
         t.retain_grad()
     outs = neck[1](pyr)
     for o, s in zip(outs, outs_seq):
-        assert torch.equal(o, s)
+        assert relerr(o, s) <= 1e-6       # bit-equal in the default mode; ARFE_GEMM_F32=1 still sums its K slices with atomics
     sum((o * c.to(dev)).sum() for o, c in zip(outs, cots)).backward()
 
     # stage 2 (AR-FPN) at the GPU pyramid
