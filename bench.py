@@ -160,7 +160,7 @@ def main():
 
     from arfe_amd import functional as Fn
     from arfe_amd.dist import GradAllReducer
-    from oracle import arfe_oracle as O      # only the synthetic-input generators and (rank 0) the cpu_baseline leg
+    from arfe_amd import synth as O          # synthetic inputs; oracle/ is imported by the cpu_baseline leg only
 
     neck, roi_head = build_modules(dev)
     neck_state = {k: v.detach().cpu().clone() for k, v in neck.state_dict().items()}

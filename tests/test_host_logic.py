@@ -232,3 +232,15 @@ def test_cascade_roi_head_builds_per_stage_modules():
                                  bbox_head=[dict(head)]))
     with pytest.raises(RuntimeError, match='train_cfg'):      # built without train_cfg: no assigners / samplers
         rh.forward_train([], [], [], [], [])
+
+
+def test_bench_inputs_equal_the_checkers():
+    """bench.py draws its synthetic pyramid / RoIs from arfe_amd.synth (the product path never imports oracle/); the CPU
+    baseline leg and the tests draw theirs from the oracle's copies: same seeds, same tensors."""
+    import torch
+    from arfe_amd import synth
+    from oracle import arfe_oracle as O
+    assert synth.PYRAMID_1333x800 == O.PYRAMID_1333x800 and synth.STRIDES == O.STRIDES
+    for a, b in zip(synth.synth_pyramid(1, 4, seed=7), O.synth_pyramid(1, 4, seed=7)):
+        assert torch.equal(a, b)
+    assert torch.equal(synth.synth_rois(2, 33, seed=5), O.synth_rois(2, 33, seed=5))
