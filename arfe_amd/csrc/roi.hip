@@ -546,7 +546,9 @@ __global__ __launch_bounds__(256) void roialign_bwd_tiles_kernel(RoiLevels L, Ro
     // floats apart), a T row 20 floats (the four 16-lane groups of a result store land 80 / 160 floats apart),
     // weight rows 8..15 are shifted by 4 floats against rows 0..7.
     __shared__ __attribute__((aligned(16))) float G_s[RB_NB][RB_CC][RB_GS];      // [roi][c][ph*8 + pw], pw = 7 zero pad
-    __shared__ float T_s[RB_CC][8][RB_TS];                                       // [c][ph (row 7 = 0)][x], one RoI at a time
+    // [c][x][ph] with the two 4-bin halves of a column swapped for x >= 8: a lane's four results are ONE 16-byte store, and the
+    // D-phase reads (lane -> column l15, bins lq and 4 + lq) of columns x and x + 8 fall on different banks
+    __shared__ __attribute__((aligned(16))) float T_s[RB_CC][RT][8];
     __shared__ __attribute__((aligned(16))) float wy_s[RB_NB][RT * 8 + 4], wx_s[RB_NB][RT * 8 + 4];
     // coarse levels hold few tiles with long RoI lists: dispatch them first (reverse tile order) and cut a long
     // list into RB_SEGS slices handled by different workgroups (those add atomically into the zeroed output)
@@ -666,16 +668,14 @@ __global__ __launch_bounds__(256) void roialign_bwd_tiles_kernel(RoiLevels L, Ro
                     t = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, t, 0, 0, 0);
                 }
                 // rows 4*lq + r of the M tile = (channel 4v + 2pr + (lq >> 1), bin 4*(lq & 1) + r), column l15
-                float* dst = &T_s[wv * 4 + pr * 2 + (lq >> 1)][4 * (lq & 1)][l15];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) dst[r * RB_TS] = t[r];
+                *reinterpret_cast<f32x4_t*>(&T_s[wv * 4 + pr * 2 + (lq >> 1)][l15][(4 * (lq & 1)) ^ ((l15 & 8) >> 1)]) = t;
             }
             const float a0 = wy_s[j][rb_wrow(l15) + lq], a1 = wy_s[j][rb_wrow(l15) + 4 + lq];
             __builtin_amdgcn_s_waitcnt(0xc07f);     // lgkmcnt(0): this wave's T rows have landed
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const float b0 = T_s[wv * 4 + c][lq][l15], b1 = T_s[wv * 4 + c][4 + lq][l15];
+                const float b0 = T_s[wv * 4 + c][l15][lq ^ ((l15 & 8) >> 1)], b1 = T_s[wv * 4 + c][l15][(4 + lq) ^ ((l15 & 8) >> 1)];
                 acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[c], 0, 0, 0);
                 acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[c], 0, 0, 0);
             }
