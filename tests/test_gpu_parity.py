@@ -962,3 +962,19 @@ def test_generic_conv_kernels_with_stage_once_switched_off():
                          timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert ' passed' in out.stdout
+
+
+def test_roialign_backward_with_sliced_lists_switched_on():
+    """ARFE_RB_SEG=<min length>,<slices> (read once per process) cuts RoI lists longer than `min` over grid.z workgroups that
+    add atomically into tiles zeroed by arfe_roialign_bwd_prezero - off by default since round 2, still the route for very
+    long lists: the RoIAlign cases must pass through it as well (fresh process)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, ARFE_RB_SEG='6,4')
+    out = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(ROOT, 'tests', 'test_gpu_parity.py'), '-q', '-x', '-m', 'gpu',
+                          '-k', 'roialign_golden or roialign_realistic or roialign_bwd_prepared or end_to_end_golden'],
+                         env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert ' passed' in out.stdout
