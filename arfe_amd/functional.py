@@ -507,9 +507,27 @@ def linear_bwd_data_op(x, w, dy, dx=None, accumulate_dx=False, mask_dx_by_x=Fals
     return dx
 
 
-def linear_bwd_weight_op(x, w, dy):
+# ---- gradient sinks: a parameter gradient produced straight into its consumer's buffer ------------------------------
+# The fused AR-RFF node returns all its parameter gradients at once, when its backward is through.  A data-parallel reducer that
+# wants a LARGE gradient on the wire earlier (fc1's weight is 51 of the head's 64 MB and exists 2 ms before the step ends)
+# registers a sink for that parameter: the kernel then writes the gradient into sink.buffer() and sink.ready() is called on the
+# stream that produced it; the node returns None for that parameter (the buffer is the reducer's p.grad already).
+_grad_sinks = {}
+
+
+def register_grad_sink(param, sink):
+    """sink: object with buffer() -> tensor shaped like param (fp32, contiguous) and ready() (called under the producing stream).
+    sink=None removes the registration."""
+    if sink is None:
+        _grad_sinks.pop(param.data_ptr(), None)
+    else:
+        _grad_sinks[param.data_ptr()] = sink
+
+
+def linear_bwd_weight_op(x, w, dy, dw=None):
     R, out_f, in_f = x.shape[0], w.shape[0], w.shape[1]
-    dw = torch.empty_like(w)
+    if dw is None:
+        dw = torch.empty_like(w)
     db = torch.empty(out_f, device=x.device)
     ws = _linear_ws(R, in_f, out_f, x.device)
     check(hip.lib().arfe_linear_bwd(R, in_f, out_f, ptr(x), ptr(w), ptr(dy), 0, 0, 0, ptr(dw), ptr(db), ptr(ws), ws.numel(),
@@ -594,7 +612,15 @@ def _rff_head_backward(saved, dcls, dreg, join=True, defer_gate_wgrads=False):
     df2 = linear_bwd_data_op(f2, wcr, dycr, mask_dx_by_x=True)                             # df2 *= [f2>0]
     dw2, db2 = side_do(lambda: linear_bwd_weight_op(f1, w2, df2))
     df1 = linear_bwd_data_op(f1, w2, df2, mask_dx_by_x=True)                               # df1 *= [f1>0]
-    dw1, db1 = side_do(lambda: linear_bwd_weight_op(z2f, w1, df1))
+    sink1 = _grad_sinks.get(w1.data_ptr())
+    if sink1 is not None:
+        def fc1_wgrad():                            # straight into the reducer's bucket, on the wire from the side stream
+            out = linear_bwd_weight_op(z2f, w1, df1, dw=sink1.buffer())
+            sink1.ready()
+            return None, out[1]
+        dw1, db1 = side_do(fc1_wgrad)
+    else:
+        dw1, db1 = side_do(lambda: linear_bwd_weight_op(z2f, w1, df1))
     dz2 = linear_bwd_data_op(z2f, w1, df1, mask_dx_by_x=True)                              # dz2 *= [z2>0]
     dwf, dbf = side_do(lambda: conv3x3_bwd_weight_op(z.data_ptr(), C * 49, R, C, w_f, dz2, ws))
     dz = torch.empty(R, C, 7, 7, device=dev)

@@ -90,6 +90,28 @@ def _worker(rank, world, port, q):
     red2.synchronize()
     ok &= all(p.grad.dtype == p.dtype and torch.allclose(p.grad.float(), torch.full_like(p, 1.5, dtype=torch.float32))
               for p in mixed)
+    # `early` parameters: a bucket of their own.  Without a registered sink (CPU tensors) the gradient arrives through autograd
+    # as for everyone else; with the sink protocol (what the fused AR-RFF node does for fc1's weight) the producer writes
+    # into sink.buffer() and calls sink.ready(), and autograd delivers nothing for that parameter
+    from arfe_amd.dist import _EarlySink
+    big, small = torch.nn.Parameter(torch.zeros(5, 3)), torch.nn.Parameter(torch.zeros(3))
+    red3 = GradAllReducer([[big, small]], early=[big])
+    ok &= len(red3.buckets) == 2 and red3.buckets[0].params[0] is big
+    for step in range(2):
+        red3.zero_grad()
+        ((big * (rank + 1)).sum() + (small * (rank + 3)).sum()).backward()
+        red3.synchronize()
+        ok &= torch.allclose(big.grad, torch.full_like(big, 1.5)) and torch.allclose(small.grad, torch.full_like(small, 3.5))
+    sink = _EarlySink(red3.buckets[0], world)
+    for step in range(2):
+        red3.zero_grad()
+        buf = sink.buffer()
+        ok &= buf.data_ptr() == big.grad.data_ptr()
+        buf.copy_(torch.full((5, 3), float(10 * (rank + 1) + step)))        # "the kernel" writes the gradient in place
+        sink.ready()                                                         # on the wire before backward is through
+        (small * (rank + 1)).sum().backward()
+        red3.synchronize()
+        ok &= torch.allclose(big.grad, torch.full_like(big, 15.0 + step)) and torch.allclose(small.grad, torch.full_like(small, 1.5))
     # max-over-ranks timing reduction used by bench.py
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -978,3 +978,22 @@ def test_roialign_backward_with_sliced_lists_switched_on():
                          env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert ' passed' in out.stdout
+
+
+def test_two_rank_gloo_step_with_early_gradient_sink():
+    """The N > 1 code path of bench.py on ONE GPU: two ranks over gloo run the step with GradAllReducer(early=[fc1.weight]); the
+    fused AR-RFF node writes fc1's weight gradient straight into the reducer's bucket and puts it on the wire from the side
+    stream (arfe_amd.functional.register_grad_sink).  Both ranks see the same data, so every averaged head gradient must equal
+    the single-process gradient (tools/probe/dist_sink_check.py asserts 1e-4)."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, ARFE_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+                          '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'tools', 'probe', 'dist_sink_check.py')],
+                         env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert out.stdout.count('sink used for fc1: True') == 2
