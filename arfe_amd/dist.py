@@ -161,9 +161,16 @@ class GradAllReducer:
                 for p in g:
                     p.grad = None
             return
+        sunk = {id(sk.bucket) for _, sk in self.sinks}
         for b in self.buckets:
             assert b.work is None, "zero_grad() while an all-reduce is in flight; call synchronize() first"
-            b.zero()
+            if id(b) in sunk:
+                # its producer overwrites the whole bucket (sink.buffer()): no 51 MB fill per step.  The gradient is dropped
+                # instead, so a backward that bypasses the sink installs a fresh tensor, which the hook copies in.
+                for p in b.params:
+                    p.grad = None
+            else:
+                b.zero()
             b.reset()
 
     def synchronize(self):
