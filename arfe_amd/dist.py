@@ -3,16 +3,21 @@ the only exchange per step is an all-reduce(sum)/world of the parameter gradient
 reference hands to MMDistributedDataParallel (mmdet/apis/train.py:124-128) and allreduce_grads
 (mmdet/core/utils/dist_utils.py:9-41).
 
-Gradients are reduced from ONE flat bucket per module group and dtype (the AR-RFF head's 64 MB, the AR-FPN's 1.1 MB):
-each parameter's .grad is a view into the bucket, so no flatten/unflatten copies happen in the step, and the
-head's bucket is put on the wire as soon as the head's backward node has produced it, while the neck's backward
-is still running (the collectives run on RCCL's own stream).
+Gradients are reduced from ONE flat bucket per module group and dtype (the AR-RFF head's 64 MB, the AR-FPN's 1.1 MB).
+`zero_grad()` drops the gradients; autograd then installs each freshly produced gradient tensor without a kernel, and when
+the last parameter of a bucket has fired, ONE `torch.cat(..., out=flat)` gathers the bucket, every `.grad` is re-pointed at
+its slice and the all-reduce is launched while the rest of the backward is still running (the collectives run on RCCL's own
+stream).  (Accumulating into pre-zeroed bucket views instead costs one small add kernel per parameter - 42 of them,
++0.2 ms per 4.0 ms step on one GPU, tools/probe/accum_overhead.py - plus the 65 MB fill.)  The largest gradient skips even
+the gather: its producer writes it straight into its bucket (gradient sink, `early=`).
 
 The view is an optimisation, not an assumption: `optimizer.zero_grad()` (set_to_none=True is torch's default) or any
-`p.grad = None` detaches a parameter from its bucket and autograd then installs a fresh tensor.  Every hook therefore
-checks that the gradient it was called for still lives in its slice and, if not, copies it there and re-points
-`p.grad`; `synchronize()` re-checks every parameter (and zero-fills the slice of one that received no gradient) before
-it waits, so what goes on the wire is always this step's gradient.  Contract: one backward per `synchronize()`."""
+`p.grad = None` detaches a parameter from its bucket and autograd then installs a fresh tensor - which is also what the
+reducer's own `zero_grad()` arranges.  When a bucket completes, `gather()` brings every gradient that does not live in its
+slice there (one cat kernel if none does, per-parameter copies for a mix of aliased and foreign tensors) and re-points
+`p.grad`; `synchronize()` does the same for a bucket the hooks never completed (and zero-fills the slice of a parameter that
+received no gradient) before it waits, so what goes on the wire is always this step's gradient.
+Contract: one backward per `synchronize()`."""
 import torch
 import torch.distributed as dist
 
@@ -37,6 +42,7 @@ class GradBucket:
         self.sunk = [False] * len(self.params)       # gradient delivered through a sink: autograd's (empty) hook call is expected
         self.pending = len(self.params)
         self.work = None
+        self.avg = False
         for i in range(len(self.params)):
             self.attach(i, keep=False)
 
@@ -67,15 +73,31 @@ class GradBucket:
         self.sunk = [False] * len(self.params)
         self.pending = len(self.params)
 
+    def gather(self):
+        """All parameters fired: bring their gradients into the flat buffer and point every .grad at its slice.  Gradients
+        that autograd installed as fresh tensors (the normal case after zero_grad()) are gathered by one cat kernel."""
+        loose = [i for i in range(len(self.params)) if not self.aliased(i)]
+        if len(loose) == len(self.params) and all(p.grad is not None and p.grad.dtype == self.flat.dtype for p in self.params):
+            with torch.no_grad():
+                torch.cat([p.grad.reshape(-1) for p in self.params], out=self.flat)
+            for i, p in enumerate(self.params):
+                p.grad = self.views[i]
+        else:
+            for i in loose:
+                self.attach(i, keep=True)
+
     def launch(self, world):
-        if world > 1 and self.work is None:
-            self.work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=True)
+        if world > 1 and self.work is None and dist.is_initialized():      # (no process group: bookkeeping-only dry run)
+            # RCCL averages inside the collective (ncclAvg); gloo has no AVG: sum, then one division pass in finish()
+            self.avg = dist.get_backend() == 'nccl'
+            self.work = dist.all_reduce(self.flat, op=dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM, async_op=True)
 
     def finish(self, world):
         if self.work is not None:
             self.work.wait()
             self.work = None
-            self.flat.div_(world)
+            if not self.avg:
+                self.flat.div_(world)
 
 
 def _split_by_dtype(params):
@@ -114,8 +136,10 @@ class GradAllReducer:
     With a single process there is nothing to exchange: no buckets are created and autograd hands each
     parameter its freshly produced gradient tensor (no accumulate-into-view pass)."""
 
-    def __init__(self, param_groups, early=()):
+    def __init__(self, param_groups, early=(), world=None):
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        if world is not None:
+            self.world = world          # measurement aid: the N > 1 bookkeeping in a single process (no communication)
         early = [p for p in early if p.requires_grad]
         early_ids = {id(p) for p in early}
         self.param_groups = [[p for p in g if p.requires_grad] for g in param_groups]
@@ -148,10 +172,10 @@ class GradAllReducer:
             if b.fired[i]:
                 raise RuntimeError(f"GradAllReducer: a second backward reached a parameter (shape {tuple(param.shape)}) before "
                                    "synchronize(); call synchronize() after every backward")
-            b.attach(i, keep=True)          # zero_grad(set_to_none=True) / p.grad=None: adopt the fresh tensor
             b.fired[i] = True
             b.pending -= 1
             if b.pending == 0:
+                b.gather()                  # fresh tensors (after zero_grad) or foreign ones: into the bucket, .grad re-pointed
                 b.launch(self.world)
         return hook
 
@@ -161,16 +185,12 @@ class GradAllReducer:
                 for p in g:
                     p.grad = None
             return
-        sunk = {id(sk.bucket) for _, sk in self.sinks}
         for b in self.buckets:
             assert b.work is None, "zero_grad() while an all-reduce is in flight; call synchronize() first"
-            if id(b) in sunk:
-                # its producer overwrites the whole bucket (sink.buffer()): no 51 MB fill per step.  The gradient is dropped
-                # instead, so a backward that bypasses the sink installs a fresh tensor, which the hook copies in.
-                for p in b.params:
-                    p.grad = None
-            else:
-                b.zero()
+            # no fill: every gradient is dropped, autograd installs fresh tensors (no accumulate kernels) and gather() or the
+            # parameter's sink brings them into the bucket
+            for p in b.params:
+                p.grad = None
             b.reset()
 
     def synchronize(self):
@@ -180,10 +200,9 @@ class GradAllReducer:
                 # bucket not completed by the hooks (frozen branch, unused parameter): a parameter without a
                 # gradient this step contributes zeros, never a stale slice; then reduce now so ranks stay in lockstep
                 for i in range(len(b.params)):
-                    if not b.fired[i]:
-                        if b.params[i].grad is None:
-                            b.views[i].zero_()
-                        b.attach(i, keep=True)
+                    if b.params[i].grad is None:
+                        b.views[i].zero_()
+                    b.attach(i, keep=True)
                 b.launch(self.world)
             b.finish(self.world)
             b.reset()
