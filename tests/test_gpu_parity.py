@@ -997,3 +997,21 @@ def test_two_rank_gloo_step_with_early_gradient_sink():
                          env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert out.stdout.count('sink used for fc1: True') == 2
+
+
+def test_rccl_one_rank_reducer_smoke():
+    """RCCL itself on the one GPU there is: a 1-rank nccl process group under the reducer's N > 1 bookkeeping (world override):
+    communicator set-up, ReduceOp.AVG, fc1's bucket launched from the side stream through the gradient sink, the other buckets
+    from the hooks, waits on the main stream.  With one rank the collectives are identities: the gradients must come out as
+    in a plain single-process step (tools/probe/rccl_one_rank.py; fresh process, own master port)."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'probe', 'rccl_one_rank.py')], env=env, cwd=ROOT,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert 'avg op True' in out.stdout

@@ -1,0 +1,49 @@
+"""RCCL smoke on ONE GPU: a 1-rank nccl process group under the N > 1 reducer bookkeeping (world override): the collectives are
+launched exactly as at N > 1 (fc1's bucket from the side stream through the gradient sink, the others from the hooks,
+ReduceOp.AVG), and with one rank they must leave the gradients unchanged."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29577')
+os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1'); os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+import torch
+import torch.distributed as dist
+import bench
+from arfe_amd import synth as O
+from arfe_amd.dist import GradAllReducer
+dev = torch.device('cuda:0'); torch.cuda.set_device(dev)
+dist.init_process_group(backend='nccl', device_id=dev)
+neck, roi_head = bench.build_modules(dev)
+torch.manual_seed(1)
+for p in list(neck.parameters()) + list(roi_head.parameters()):
+    p.data.add_(0.01 * torch.randn_like(p))
+xs = [x.to(dev).requires_grad_(True) for x in O.synth_pyramid(1, 256, sizes=((40, 64), (20, 32), (10, 16), (5, 8), (3, 4)))]
+rois = torch.tensor([[0, 8., 8., 120., 90.], [0, 30., 20., 200., 150.], [0, 5., 100., 250., 140.], [0, 100., 10., 140., 150.]] * 16, device=dev)
+cc, cr = torch.ones(64, 81, device=dev), torch.ones(64, 320, device=dev)
+params = list(roi_head.bbox_head.parameters()) + list(neck.parameters())
+res = roi_head._bbox_forward(neck(xs), rois)
+torch.autograd.backward([res['cls_score'], res['bbox_pred']], [cc, cr])
+torch.cuda.synchronize()
+ref = [p.grad.detach().clone() for p in params]
+for p in params: p.grad = None
+red = GradAllReducer([list(roi_head.bbox_head.parameters()), list(neck.parameters())],
+                     early=[roi_head.bbox_head.shared_fcs[0].weight], world=2)
+for _ in range(3):
+    red.zero_grad()
+    for x in xs: x.grad = None
+    res = roi_head._bbox_forward(neck(xs), rois)
+    torch.autograd.backward([res['cls_score'], res['bbox_pred']], [cc, cr])
+    red.synchronize()
+torch.cuda.synchronize()
+# (phi's bias gradient is mathematically zero - a constant added to every key shifts a softmax row's logits equally - so its
+# computed value is rounding noise that differs run to run (as do theta's / phi's weight gradients at the 1e-5 level: atomic
+# split-K sums under heavy cancellation): errors are scaled by max(|tensor|, 1 % of the largest gradient))
+gmax = max(float(r.abs().max()) for r in ref)
+names = [n for n, _ in roi_head.bbox_head.named_parameters()] + ['neck.' + n for n, _ in neck.named_parameters()]
+worst = 0.0
+for n, p, r in zip(names, params, ref):
+    e = float((p.grad - r).abs().max()) / max(float(r.abs().max()), 1e-2 * gmax)
+    worst = max(worst, e)
+    if e > 1e-4: print(f'  off: {n} err {e:.2e} |ref|max {float(r.abs().max()):.3e} gmax {gmax:.3e}')
+print(f"rccl 1-rank: buckets {len(red.buckets)}, sink {len(red.sinks)}, avg op {red.buckets[0].avg}, worst relative difference {worst:.2e}")
+assert worst < 1e-3 and red.buckets[0].avg
+dist.destroy_process_group()
