@@ -1000,9 +1000,16 @@ extern "C" int32_t arfe_nonlocal_bwd_wcat(int32_t B, int32_t C, int32_t L, const
         LoadRowMajorK la{dtpg, 0, 3 * CL, L, 3 * C, L};
         LoadRowMajorK lb{m, 0, CL, L, C, L};
         EpiPlain e = epi_plain(dwcat, 0, C);
-        e.atomic = 1;
-        rc = launch_gemm_auto(3 * C, C, L, B, 1, pick_splitk(3 * C, C, 1, B * kstepsL), la, lb, e, st);
+        // per-slice slabs + fixed-order reduce (the data path, the slabs' other user, is through when this runs): theta's and
+        // phi's weight gradients are sums under heavy cancellation, and atomic partial sums made them differ by 1e-5 run to run
+        bool by_slabs = false;
+        rc = gemm_try_slabs(3 * C, C, L, B, 1, la, lb, e, st, nl_slab_base(workspace, B, C, L), nl_slab_floats(B, C, L), &by_slabs);
         if (rc) return rc;
+        if (!by_slabs) {
+            e.atomic = 1;
+            rc = launch_gemm_auto(3 * C, C, L, B, 1, pick_splitk(3 * C, C, 1, B * kstepsL), la, lb, e, st);
+            if (rc) return rc;
+        }
         dim3 grid(3 * C, B);
         hipLaunchKernelGGL(reduce_mid_kernel, grid, dim3(256), 0, st, dtpg, (const float*)nullptr, dbcat, B, 3 * CL, L, 1);
         ARFE_CHECK_LAUNCH();
