@@ -214,6 +214,28 @@ __global__ __launch_bounds__(1024) void roi_bin_scan_kernel(const int* __restric
     if (threadIdx.x == 0) offsets[ntiles] = carry;
 }
 
+// The fill above appends through atomic cursors, so a tile's list comes out in a different order every run - and with it the
+// order in which the backward adds the RoIs' contributions.  One wave per tile puts its list in RoI order (rank by counting
+// in LDS; lists longer than RL_SORT_MAX keep their arrival order), which makes the backward bit-reproducible.
+constexpr int RL_SORT_MAX = 2048;
+__global__ __launch_bounds__(64) void roi_list_sort_kernel(const int* __restrict__ offsets, int* __restrict__ list,
+                                                          int* __restrict__ lmeta) {
+    __shared__ int id_s[RL_SORT_MAX], meta_s[RL_SORT_MAX];
+    const int tile = blockIdx.x, lane = threadIdx.x;
+    const int beg = offsets[tile], n = offsets[tile + 1] - beg;
+    if (n < 2 || n > RL_SORT_MAX) return;
+    for (int i = lane; i < n; i += 64) { id_s[i] = list[beg + i]; meta_s[i] = lmeta[beg + i]; }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < n; i += 64) {
+        const int mine = id_s[i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) rank += id_s[j] < mine ? 1 : 0;      // ids are unique within a list
+        list[beg + rank] = mine;
+        lmeta[beg + rank] = meta_s[i];
+    }
+}
+
 // 1-D bilinear weight of feature index `target` for output bin `pb`: sum over the bin's grid samples
 __device__ __forceinline__ float axis_weight(float start, float bin, int grid, int pb, int n, int target) {
     float w = 0.f;
@@ -940,6 +962,8 @@ extern "C" int32_t arfe_roialign_bwd_prepare(const arfe_pyramid_t* pyr, const in
     if (p.nroi > 0) {
         hipLaunchKernelGGL((roi_bin_kernel<true>), dim3(cdiv(p.nroi, 256)), dim3(256), 0, st, L, S, p.T, pooled, p.counts,
                            (const int*)p.offsets, p.cursors, p.list, (const RoiWeightHdr*)p.hdr, p.lmeta);
+        ARFE_CHECK_LAUNCH();
+        hipLaunchKernelGGL(roi_list_sort_kernel, dim3(p.ntiles), dim3(64), 0, st, (const int*)p.offsets, p.list, p.lmeta);
         ARFE_CHECK_LAUNCH();
     }
     return ARFE_OK;

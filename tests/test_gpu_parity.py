@@ -4,6 +4,8 @@ same seeded inputs, and against the golden vectors generated from the reference 
 Tolerance: north_star asks for 1e-3 relative in fp32 (max|a-b|/max|b|).  The streaming kernels are exact fp32
 and the dense contractions run as bf16x3 split MFMA (~1e-5 relative), so the asserts are set 3-10x tighter than
 the north-star bound (TOL / TOL_GRAD) to catch indexing bugs; integer/index results must be bit-exact."""
+import os
+
 import pytest
 import torch
 
@@ -264,7 +266,10 @@ def test_roialign_bwd_prepared_route_equals_single_call(Fn, O, dev):
     ws = Fn.roialign_bwd_prepare_op(feats, O.STRIDES, sets, lv)
     two = Fn.roialign_bwd_op(shapes, O.STRIDES, sets, lv, gout, prepared=ws)
     for a, b in zip(one, two):
-        assert relerr(a, b) <= 1e-6         # the tile lists are filled through atomic cursors: summation order varies
+        # the tile lists are filled through atomic cursors and then put in RoI order (roi_list_sort_kernel): two runs add the
+        # RoIs of a tile in the same order, and with no list sliced (the default) nothing is summed atomically
+        assert torch.equal(a, b) or os.environ.get('ARFE_RB_SEG')
+        assert relerr(a, b) <= 1e-6
     # the same in three calls: the atomically summed tiles zeroed ahead of time into early-allocated gradients
     pz = Fn.roialign_bwd_prezero_op(shapes, O.STRIDES, sets, ws)
     three = Fn.roialign_bwd_op(shapes, O.STRIDES, sets, lv, gout, prepared=ws, prezeroed=pz)
