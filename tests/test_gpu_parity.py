@@ -1018,5 +1018,7 @@ def test_rccl_one_rank_reducer_smoke():
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'probe', 'rccl_one_rank.py')], env=env, cwd=ROOT,
                          capture_output=True, text=True, timeout=600)
+    if 'RCCL_UNAVAILABLE' in out.stdout:
+        pytest.skip('no RCCL bootstrap here: ' + out.stdout[-300:])
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert 'avg op True' in out.stdout
