@@ -112,6 +112,23 @@ def _worker(rank, world, port, q):
         (small * (rank + 1)).sum().backward()
         red3.synchronize()
         ok &= torch.allclose(big.grad, torch.full_like(big, 15.0 + step)) and torch.allclose(small.grad, torch.full_like(small, 1.5))
+    # a parameter whose node hands autograd None (torch still runs its post-accumulate hook): the bucket completes, the
+    # parameter contributes zeros and keeps a bucket view as its gradient
+    class _NoGradFor2nd(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, a, b):
+            return a * 2 + b.sum() * 0
+
+        @staticmethod
+        def backward(ctx, g):
+            return g * 2, None
+    pa, pb = torch.nn.Parameter(torch.ones(3)), torch.nn.Parameter(torch.ones(2))
+    red4 = GradAllReducer([[pa, pb]])
+    red4.zero_grad()
+    (_NoGradFor2nd.apply(pa, pb) * (rank + 1)).sum().backward()
+    red4.synchronize()
+    ok &= torch.allclose(pa.grad, torch.full((3,), 3.0)) and pb.grad is not None and float(pb.grad.abs().max()) == 0.0
+    ok &= pb.grad.data_ptr() == red4.buckets[0].views[1].data_ptr()
     # max-over-ranks timing reduction used by bench.py
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
