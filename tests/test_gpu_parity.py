@@ -364,6 +364,36 @@ def test_linear_ops_with_and_without_splitk_scratch(Fn, dev, R, in_f, out_f):
         assert relerr(dx, dx_ref.float()) <= TOL and relerr(dw, dw_ref.float()) <= TOL and relerr(db, db_ref.float()) <= TOL
 
 
+@pytest.mark.parametrize("classes,agnostic,R", [(7, True, 33), (3, False, 64), (80, True, 40)])
+def test_rff_head_predictor_shapes_match_oracle(O, dev, classes, agnostic, R):
+    """The stacked predictor contraction ([classes + 1; 4 or 4 * classes] rows) for class counts and RoI counts other than the
+    bench's, class-agnostic regression included: MultiBBoxHead forward + backward against the oracle's head."""
+    import arfe_amd
+    torch.manual_seed(classes + R)
+    C, fc = 32, 40
+    head = arfe_amd.build_head(dict(type='MultiRoIsBBoxHead', in_channels=C, conv_out_channels=C, fc_out_channels=fc,
+                                    roi_feat_size=7, num_classes=classes, reg_class_agnostic=agnostic)).to(dev)
+    for p in head.parameters():
+        p.data.normal_(0, 0.05)
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(R, 3 * C, 7, 7, generator=g)
+    xo = x.clone().requires_grad_(True)
+    po = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in head.state_dict().items()}
+    co, ro = O.rff_head(xo, po)
+    assert co.shape == (R, classes + 1) and ro.shape == (R, 4 if agnostic else 4 * classes)
+    gc, gr = torch.randn(co.shape, generator=g), torch.randn(ro.shape, generator=g)
+    ((co * gc).sum() + (ro * gr).sum()).backward()
+    xd = x.to(dev).requires_grad_(True)
+    cd, rd = head(xd)
+    assert relerr(cd, co.detach()) <= TOL and relerr(rd, ro.detach()) <= TOL
+    ((cd * gc.to(dev)).sum() + (rd * gr.to(dev)).sum()).backward()
+    # gradients in L2: with random weights a pre-activation within rounding of zero may flip its ReLU between the two
+    # implementations, which moves single elements by a whole term (max-norm 5e-3 in one of these cases) but not the tensor
+    assert relerr_l2(xd.grad, xo.grad) <= 2e-3
+    for k, v in head.named_parameters():
+        assert relerr_l2(v.grad, po[k].grad) <= 2e-3, k
+
+
 def test_rff_head_with_prepacked_weights_equals_plain_call(Fn, dev):
     """MultiBBoxHead.prepack() (weight re-layout launched early on the side stream) changes scheduling only."""
     import arfe_amd
