@@ -145,6 +145,7 @@ class GradAllReducer:
         self.param_groups = [[p for p in g if p.requires_grad] for g in param_groups]
         self.buckets = []
         self.sinks = []
+        self._hooks = []
         if self.world > 1:
             for p in early:
                 b = GradBucket([p])
@@ -159,14 +160,32 @@ class GradAllReducer:
                 self.buckets += [GradBucket(sub) for sub in _split_by_dtype(rest)]
             for b in self.buckets:
                 for p in b.params:
-                    p.register_post_accumulate_grad_hook(self._make_hook(b))
+                    self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(b)))
+
+    def close(self):
+        """Unregister the gradient sinks and hooks (a reducer that is dropped must not keep receiving gradients)."""
+        from . import functional as Fn
+        for p, _sink in self.sinks:
+            Fn.register_grad_sink(p, None)
+        self.sinks = []
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def _make_hook(self, b):
         def hook(param):
             i = b.index[id(param)]
             if b.sunk[i]:
-                # the producer wrote this gradient into the bucket and put it on the wire (sink); autograd still runs the
-                # parameter's hooks once with the None the node returned for it
+                # the producer wrote this gradient into the bucket and put it on the wire (sink) and the node returned None
+                # for the parameter.  AccumulateGrad returns early on an undefined gradient, so this hook normally does NOT
+                # run for a sunk parameter (reset() clears the flag); should a later node deliver a gradient for it in the
+                # same backward anyway, it is not counted twice
                 b.sunk[i] = False
                 return
             if b.fired[i]:

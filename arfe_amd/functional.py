@@ -54,6 +54,18 @@ def probe_results_ms():
     return {k: [a.elapsed_time(b) for a, b in v] for k, v in _Probe.records.items()}
 
 
+# Parity tooling: when a dict is installed here the forward passes drop references to the tensors that hold their
+# discrete choices (pooling argmax, gate maps, ReLU outputs) into it, so a parity test can evaluate its CPU checker under
+# the same choices.  None (the default) costs nothing.
+_decision_tap = None
+
+
+def tap_decisions(target):
+    """target: a dict to fill during the next forward passes, or None to switch the tap off."""
+    global _decision_tap
+    _decision_tap = target
+
+
 def _empty_like_levels(xs):
     return [torch.empty_like(x) for x in xs]
 
@@ -254,6 +266,8 @@ class ARFPNFunction(torch.autograd.Function):
         bsf, saved = nonlocal_fwd_op(m, wt, bt, wp, bp, wg, bg, wo, bo)
         join_side(dev)
         outs = fpn_scatter_op(xs, bsf, a, b, refine_level)
+        if _decision_tap is not None:
+            _decision_tap.update(argmax=argmax, gate_a=a, gate_b=b)
         ctx.refine_level, ctx.n = refine_level, n
         if need_grad:
             ctx.save_for_backward(*xs, *w1, *w2, wt, wp, wg, wo, m, bsf, *a, *b, *saved,
@@ -512,16 +526,30 @@ def linear_bwd_data_op(x, w, dy, dx=None, accumulate_dx=False, mask_dx_by_x=Fals
 # wants a LARGE gradient on the wire earlier (fc1's weight is 51 of the head's 64 MB and exists 2 ms before the step ends)
 # registers a sink for that parameter: the kernel then writes the gradient into sink.buffer() and sink.ready() is called on the
 # stream that produced it; the node returns None for that parameter (the buffer is the reducer's p.grad already).
-_grad_sinks = {}
+_grad_sinks = {}        # id(parameter) -> (weakref to the parameter, sink)
 
 
 def register_grad_sink(param, sink):
     """sink: object with buffer() -> tensor shaped like param (fp32, contiguous) and ready() (called under the producing stream).
-    sink=None removes the registration."""
+    sink=None removes the registration.  The registry is keyed by the Parameter OBJECT (its id, validated through a weak
+    reference at lookup), not by its storage address: swapping `p.data` neither loses the sink nor lets a stale entry match
+    an unrelated weight at a reused address, and a dead parameter's entry can never be hit."""
+    import weakref
     if sink is None:
-        _grad_sinks.pop(param.data_ptr(), None)
+        _grad_sinks.pop(id(param), None)
     else:
-        _grad_sinks[param.data_ptr()] = sink
+        _grad_sinks[id(param)] = (weakref.ref(param), sink)
+
+
+def grad_sink_of(t):
+    """The sink registered for exactly this tensor object (an autograd leaf handed to a Function's forward), or None."""
+    e = _grad_sinks.get(id(t))
+    if e is None:
+        return None
+    if e[0]() is not t:             # the id was recycled by another object: the registration is dead
+        _grad_sinks.pop(id(t), None)
+        return None
+    return e[1]
 
 
 def linear_bwd_weight_op(x, w, dy, dw=None):
@@ -581,10 +609,12 @@ def _rff_head_forward(x, params, packs):
     ycr = linear_fwd_op(f2, wcr, bcr, False)
     nc = wc.shape[0]
     cls, reg = ycr[:, :nc], ycr[:, nc:]
+    if _decision_tap is not None:
+        _decision_tap.update(lw=lw, lh=lh, z2=z2, f1=f1, f2=f2)
     return cls, reg, (x, w_wh, w_hh, w_f, w1, w2, wcr, bc, lw, lh, z, z2, f1, f2, pk_wh, pk_hh, pk_f)
 
 
-def _rff_head_backward(saved, dcls, dreg, join=True, defer_gate_wgrads=False):
+def _rff_head_backward(saved, dcls, dreg, join=True, defer_gate_wgrads=False, sink1=None):
     """-> (dx [R,3C,7,7], 14 parameter gradients in forward-argument order, keep-alive tensors[, late]).
     defer_gate_wgrads: do not launch the weight gradients of wh_conv / hh_conv; `late()` launches them on the side stream
     (ordered after everything enqueued on the current stream at THAT moment) and fills their four slots of the list.
@@ -612,8 +642,7 @@ def _rff_head_backward(saved, dcls, dreg, join=True, defer_gate_wgrads=False):
     df2 = linear_bwd_data_op(f2, wcr, dycr, mask_dx_by_x=True)                             # df2 *= [f2>0]
     dw2, db2 = side_do(lambda: linear_bwd_weight_op(f1, w2, df2))
     df1 = linear_bwd_data_op(f1, w2, df2, mask_dx_by_x=True)                               # df1 *= [f1>0]
-    sink1 = _grad_sinks.get(w1.data_ptr())
-    if sink1 is not None:
+    if sink1 is not None:           # fc1's gradient sink, looked up by the forward on the parameter object itself
         def fc1_wgrad():                            # straight into the reducer's bucket, on the wire from the side stream
             out = linear_bwd_weight_op(z2f, w1, df1, dw=sink1.buffer())
             sink1.ready()
@@ -646,7 +675,7 @@ def _rff_head_backward(saved, dcls, dreg, join=True, defer_gate_wgrads=False):
         join_side(dev)
     # (dz2, dz, dlw, dlh, ws are read by side-stream kernels that may still be queued when join=False: they were allocated
     # on the current stream, whose allocator only re-issues them to work enqueued after the caller's join)
-    keep = (dz2, dz, dlw, dlh, ws, df1, df2)
+    keep = (dz2, dz, dlw, dlh, ws, df1, df2, dycr)
     if defer_gate_wgrads:
         return dx, pg, keep, gate_wgrads
     return dx, pg, keep
@@ -661,6 +690,7 @@ class RFFHeadFunction(torch.autograd.Function):
     def forward(ctx, x, w_wh, b_wh, w_hh, b_hh, w_f, b_f, w1, b1, w2, b2, wc, bc, wr, br, pk_wh=None, pk_hh=None,
                 pk_f=None):
         x = x.contiguous()
+        ctx.sink1 = grad_sink_of(w1) if w1.is_contiguous() else None
         params = [p.contiguous() for p in (w_wh, b_wh, w_hh, b_hh, w_f, b_f, w1, b1, w2, b2, wc, bc, wr, br)]
         hip.require_f32_cuda(x, *params)
         packs = None
@@ -673,7 +703,7 @@ class RFFHeadFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dcls, dreg):
-        dx, pg, _keep = _rff_head_backward(ctx.saved_tensors, dcls, dreg, join=True)
+        dx, pg, _keep = _rff_head_backward(ctx.saved_tensors, dcls, dreg, join=True, sink1=ctx.sink1)
         return (dx, *pg, None, None, None)
 
 
@@ -697,6 +727,8 @@ class RFFExtractHeadFunction(torch.autograd.Function):
         feats = [f.contiguous() for f in t[:nfeat]]
         roi_sets = [r.contiguous() for r in t[nfeat:nfeat + 3]]
         levels = [l.contiguous() for l in t[nfeat + 3:nfeat + 6]]
+        w1_leaf = t[nfeat + 6 + 6]
+        ctx.sink1 = grad_sink_of(w1_leaf) if w1_leaf.is_contiguous() else None
         params = [p.contiguous() for p in t[nfeat + 6:nfeat + 20]]
         hip.require_f32_cuda(*feats, *roi_sets, *params)
         dev = feats[0].device
@@ -736,7 +768,7 @@ class RFFExtractHeadFunction(torch.autograd.Function):
         # (Measured: holding the gate convs' weight gradients back until the data-gradient chain is through, so that they
         # share the chip with the RoIAlign backward only, is SLOWER - that kernel's two contractions run on the fp32 matrix
         # pipe, and the two kinds of MFMA work just queue: 620 + 549 us side by side against 450 + 2 x 217 alone.)
-        dx, pg, keep = _rff_head_backward(saved, dcls, dreg, join=False)
+        dx, pg, keep = _rff_head_backward(saved, dcls, dreg, join=False, sink1=ctx.sink1)
         dfeats = [None] * nfeat
         if any(ctx.needs_input_grad[4:4 + nfeat]):
             if dfeat is not None:             # a consumer of bbox_feats other than the head (not on the AR path)

@@ -294,6 +294,18 @@ def ar_rff_bbox_forward(bbox_roi_extractor, bbox_head, x, rois):
     return dict(cls_score=cls_score, bbox_pred=bbox_pred, bbox_feats=bbox_feats)
 
 
+def cascade_refine_labels(bbox_head, labels, cls_score):
+    """The class whose box refines each RoI for the next cascade stage (cascade_roi_head.py:274-280 passes the target labels).
+    Background targets carry label == num_classes; with a class-SPECIFIC regressor (reg_class_agnostic=False, the BBoxHead
+    default) regress_by_class would gather columns 4*num_classes.. of a [n, 4*num_classes] prediction - an index error on the
+    CPU and a device-side assert on the GPU.  The reference at HEAD has that hole (its cascade configs are all class-agnostic,
+    where the labels are not used); background RoIs take the best foreground class instead, as upstream mmdetection does."""
+    if bbox_head.reg_class_agnostic:
+        return labels
+    nc = bbox_head.num_classes
+    return torch.where(labels == nc, cls_score[:, :nc].argmax(1), labels)
+
+
 @HEADS.register_module()
 class StandardRoIHead(nn.Module):
     """Only the bbox feature path of the reference's StandardRoIHead is in scope: `_bbox_forward` with the
@@ -455,6 +467,8 @@ class CascadeRoIHead(nn.Module):
             if i < self.num_stages - 1:
                 pos_is_gts = [res.pos_is_gt for res in sampling_results]
                 with torch.no_grad():
-                    proposal_list = self.bbox_head[i].refine_bboxes(bbox_results['rois'], bbox_results['bbox_targets'][0],
+                    roi_labels = cascade_refine_labels(self.bbox_head[i], bbox_results['bbox_targets'][0],
+                                                       bbox_results['cls_score'])
+                    proposal_list = self.bbox_head[i].refine_bboxes(bbox_results['rois'], roi_labels,
                                                                     bbox_results['bbox_pred'], pos_is_gts, img_metas)
         return losses

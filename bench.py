@@ -101,11 +101,41 @@ def build_modules(dev):
     return neck.to(dev), roi_head.to(dev)
 
 
-def cpu_baseline(batch, rois_per_img, iters, neck_state, head_state):
-    """The oracle (CPU restatement, kind='port') on the host cores, same synthetic workload."""
+def host_cpu_share():
+    """Cores this process may use: the scheduler affinity, cut by a cgroup CPU quota if one is set (os.cpu_count() reports the
+    whole host on the GPU box; the 1-GPU lease is a 16-core share).  ARFE_CPU_THREADS overrides."""
+    if os.environ.get('ARFE_CPU_THREADS'):
+        return max(1, int(os.environ['ARFE_CPU_THREADS']))
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if q != 'max':
+            quota = float(q) / float(per)
+    except Exception:
+        try:
+            q = float(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            per = float(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    if quota is not None:
+        n = min(n, max(1, int(quota + 0.5)))
+    elif n > 32:
+        n = 16        # no affinity mask and no quota visible: stay on the 1-GPU box's documented 16-core share
+    return n
+
+
+def cpu_baseline(batch, rois_per_img, iters, neck_state, head_state, device_run=None):
+    """The oracle (CPU restatement, kind='port') on the host cores, same synthetic workload.
+    device_run: callable -> the device's outputs / gradients / decisions of the same step (oracle.parity.device_step); the
+    oracle pass this leg runs anyway is then used as the checker too -> (cpu_baseline dict, parity dict or None)."""
     from oracle import arfe_oracle as O
-    # the 1-GPU box gives this job a 16-core CPU share (os.cpu_count() reports the whole host)
-    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    from oracle import parity as P
+    threads = host_cpu_share()
+    torch.set_num_threads(threads)
+    O.set_roi_align_threads(threads)
     pn = {k: v.clone().requires_grad_(True) for k, v in neck_state.items()}
     ph = {k: v.clone().requires_grad_(True) for k, v in head_state.items()}
     xs = [x.requires_grad_(True) for x in O.synth_pyramid(batch, 256, seed=1234)]
@@ -113,13 +143,15 @@ def cpu_baseline(batch, rois_per_img, iters, neck_state, head_state):
     g = torch.Generator().manual_seed(99)
     c1 = torch.randn(rois.shape[0], 81, generator=g)
     c2 = torch.randn(rois.shape[0], 320, generator=g)
+    last = {}
 
     def step():
         for t in xs + list(pn.values()) + list(ph.values()):
             t.grad = None
-        feats = O.arfpn_forward(xs, pn, 2)
-        cls, reg = O.rff_head(O.roi_extract3(feats, rois), ph)
+        feats, parts_n = O.arfpn_forward(xs, pn, 2, return_parts=True)
+        cls, reg, parts_h = O.rff_head(O.roi_extract3(feats, rois), ph, return_parts=True)
         torch.autograd.backward([cls, reg], [c1, c2])
+        last.update(cls=cls, reg=reg, parts_n=parts_n, parts_h=parts_h)
 
     step()   # warm-up
     ts = []
@@ -129,14 +161,56 @@ def cpu_baseline(batch, rois_per_img, iters, neck_state, head_state):
         ts.append(time.perf_counter() - t0)
     ts.sort()
     med = ts[len(ts) // 2]
-    return {"value": round(batch / med, 4), "unit": "imgs/s", "cores": torch.get_num_threads(), "kind": "port",
+    base = {"value": round(batch / med, 4), "unit": "imgs/s", "cores": threads, "kind": "port",
             "sample": f"{iters} timed + 1 warm-up fwd+bwd passes of the same workload (B={batch}, R={rois.shape[0]}), "
-                      f"median {med:.2f} s/step; oracle/arfe_oracle.py (torch-CPU fp32) + oracle C RoIAlign (1 thread)"}
+                      f"median {med:.2f} s/step; oracle/arfe_oracle.py (torch-CPU fp32) + oracle C RoIAlign, {threads} threads each"}
+    parity = None
+    if device_run is not None:
+        # the checker: this leg's last free-running pass + one pass under the device's ReLU / argmax choices (oracle/parity.py)
+        free = dict(cls=last['cls'].detach(), reg=last['reg'].detach(), dxs=[x.grad for x in xs],
+                    dneck={k: v.grad for k, v in pn.items()}, dhead={k: v.grad for k, v in ph.items()},
+                    decisions=O.decisions_of(xs, last['parts_n'], last['parts_h'], 2))
+        rep = P.compare(device_run(P), [x.detach() for x in xs], rois, {k: v.detach() for k, v in pn.items()},
+                        {k: v.detach() for k, v in ph.items()}, c1, c2, free=free)
+        parity = {k: (float(f"{v:.3e}") if isinstance(v, float) else v) for k, v in rep.items()}
+    return base, parity
+
+
+def self_launch(args):
+    """`bench.py --gpus N` (N > 1) started WITHOUT a launcher: start the N ranks here as a child torch.distributed.run job
+    (reference: tools/dist_train.sh:1-9) and relay rank 0's JSON line.  Runs before anything touches the GPU in this
+    process; the child is a subprocess, never an exec."""
+    import socket
+    import subprocess
+    backend = os.environ.get('ARFE_DIST_BACKEND', 'nccl')
+    ndev = torch.cuda.device_count()            # (does not initialise the GPU on this image)
+    if backend == 'nccl' and ndev < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} needs {args.gpus} GPUs over RCCL, this node shows {ndev} "
+              f"(ARFE_DIST_BACKEND=gloo rehearses the N > 1 path with ranks sharing GPUs)", file=sys.stderr)
+        return 2
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '4')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    sys.stdout.write(r.stdout)
+    sys.stdout.flush()
+    return r.returncode
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(args))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        # never measure fewer GPUs than the line claims
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus N` (it launches "
+                 f"its own ranks) or through torch.distributed.run with --nproc-per-node equal to --gpus")
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
@@ -152,8 +226,8 @@ def main():
             dist.init_process_group(backend='nccl', device_id=dev)
         else:
             dist.init_process_group(backend=backend)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if world > 1:
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
         # communicator set-up (lazy in RCCL) must not land in the timed region even with --warmup 0
         dist.all_reduce(torch.zeros(1, device=dev))
         torch.cuda.synchronize()
@@ -249,6 +323,8 @@ def main():
             "dtype": ("f16 storage at module boundaries, " if args.fp16 else "") +
                      ("f32" if f32_mode else "f32 (dense contractions as bf16x3 split MFMA, fp32 accumulate)"),
             "data": "synthetic",
+            "dist": {"backend": (dist.get_backend() if world > 1 else None), "world_size": (dist.get_world_size() if world > 1 else 1),
+                     "launcher": os.environ.get('TORCHELASTIC_RUN_ID') is not None},
             "config": {"workload": "Faster R-CNN R50 AR-FPN + AR-RFF hot path (BASELINE configs[2]): WFPNDualSpatial "
                                    "(refine_level 2) + 3-RoI RoIAlign + MultiRoIsBBoxHead, fwd+bwd + grad all-reduce",
                        "per_gpu_batch": B, "global_batch": world * B, "rois_per_gpu": R, "channels": 256,
@@ -273,7 +349,11 @@ def main():
                                   "conv3x3_fwd_and_dgrad": round(sum(conv_ms) / args.steps, 4)},
         }
         if world == 1 and not args.no_cpu_baseline and not args.fp16:
-            out["cpu_baseline"] = cpu_baseline(B, args.rois_per_img, args.cpu_iters, neck_state, head_state)
+            # (outside the timed region) the CPU leg doubles as the checker of this very workload
+            def device_run(P):
+                return P.device_step(neck, roi_head, xs, rois, cot_cls, cot_reg)
+            out["cpu_baseline"], out["parity"] = cpu_baseline(B, args.rois_per_img, args.cpu_iters, neck_state, head_state,
+                                                              device_run)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -25,7 +25,7 @@ def build_c_oracle(force=False):
     src = os.path.join(HERE, "roi_align_oracle.c")
     out = os.path.join(out_dir, "liboracle.so")
     if force or not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
-        subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-o", out, src, "-lm"])
+        subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-pthread", "-o", out, src, "-lm"])
     return out
 
 

@@ -486,37 +486,44 @@ def test_end_to_end_medium_matches_oracle(O, dev):
     roi_head.bbox_head.load_state_dict({k: v.clone() for k, v in ph.items()})
     xs_cpu = [torch.randn(B, C, h, w, generator=g) for h, w in sizes]
     rois = O.synth_rois(B, 110, img_w=608, img_h=400, seed=9)
-    # reference on the CPU
-    pnr = {k: v.clone().requires_grad_(True) for k, v in pn.items()}
-    phr = {k: v.clone().requires_grad_(True) for k, v in ph.items()}
-    xr = [x.clone().requires_grad_(True) for x in xs_cpu]
-    feats_r = O.arfpn_forward(xr, pnr, refine_level=2)
-    cls_r, reg_r = O.rff_head(O.roi_extract3(list(feats_r), rois), phr)
-    cot_c, cot_r = torch.randn(cls_r.shape, generator=g), torch.randn(reg_r.shape, generator=g)
-    ((cls_r * cot_c).sum() + (reg_r * cot_r).sum()).backward()
-    # HIP path
+    from oracle import parity as P
+    cot_c, cot_r = torch.randn(rois.shape[0], 81, generator=g), torch.randn(rois.shape[0], 320, generator=g)
     xs = [x.clone().to(dev).requires_grad_(True) for x in xs_cpu]
-    res = roi_head._bbox_forward(neck(xs), rois.to(dev))
-    assert relerr(res['cls_score'], cls_r.detach()) <= TOL and relerr(res['bbox_pred'], reg_r.detach()) <= TOL
-    ((res['cls_score'] * cot_c.to(dev)).sum() + (res['bbox_pred'] * cot_r.to(dev)).sum()).backward()
+    got = P.device_step(neck, roi_head, xs, rois.to(dev), cot_c.to(dev), cot_r.to(dev))
+    rep = P.compare(got, xs_cpu, rois, pn, ph, cot_c, cot_r)
+    print(rep)
+    # forward in max-norm; the ReLU / argmax choices that differ are counted; gradients in max-norm (north_star's bound) against
+    # the oracle evaluated under the device's choices - no L2 allowance for flipped masks any more
+    assert rep['max_rel_fwd'] <= TOL, rep
+    assert rep['mask_flips'] <= max(3, 20e-6 * rep['decisions']), rep
+    assert rep['max_rel_grad_agreeing'] <= NORTH_STAR_TOL, rep
 
-    # Gradients: at this size a couple of ReLU masks per million elements differ between any two fp32 implementations
-    # (see conftest.relerr_l2) and a flipped pixel perturbs everything downstream of it (all weights of its channel, and
-    # through the NonLocal attention every pixel of the pyramid gradient), so the bound is on the L2 error.
-    def close(a, b, what, tol=2e-3):
-        if b is None:       # the reference left no gradient (a level no RoI touched): ours must be exactly zero
-            assert a is None or float(a.abs().max()) == 0.0, what
-            return
-        assert relerr_l2(a, b) <= tol, (what, relerr_l2(a, b))
 
-    for i in range(5):
-        close(xs[i].grad, xr[i].grad, f'dx{i}')
-    for k, v in neck.named_parameters():
-        if k == 'refine.phi.conv.bias':        # mathematically zero gradient (softmax shift invariance): noise only
-            continue
-        close(v.grad, pnr[k].grad, k, 5e-3)
-    for k, v in roi_head.bbox_head.named_parameters():
-        close(v.grad, phr[k].grad, k, 5e-3)     # a flipped pixel feeds every weight / the bias of its channel
+def test_bench_workload_full_size_matches_oracle(O, dev):
+    """The exact bench.py step (BASELINE configs[2] hot path: B=2, C=256, 1333x800 pyramid, R=1024, seeds 1234 / 99,
+    init_weights parameters) on the HIP path against the oracle, as a whole: cls/reg in max-norm against the free-running
+    oracle; the ReLU / argmax choices that differ between the two forward passes COUNTED; every gradient in max-norm
+    (north_star's 1e-3) against the oracle evaluated under the device's choices (oracle/parity.py)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from oracle import parity as P
+    B, per_img = 2, 512
+    neck, roi_head = bench.build_modules(dev)
+    pn = {k: v.detach().cpu().clone() for k, v in neck.state_dict().items()}
+    ph = {k: v.detach().cpu().clone() for k, v in roi_head.bbox_head.state_dict().items()}
+    xs_cpu = O.synth_pyramid(B, 256, seed=1234)
+    rois = O.synth_rois(B, per_img, seed=1234)
+    g = torch.Generator().manual_seed(99)
+    cc, cr = torch.randn(B * per_img, 81, generator=g), torch.randn(B * per_img, 320, generator=g)
+    xs = [x.to(dev).requires_grad_(True) for x in xs_cpu]
+    got = P.device_step(neck, roi_head, xs, rois.to(dev), cc.to(dev), cr.to(dev))
+    rep = P.compare(got, xs_cpu, rois, pn, ph, cc, cr)
+    print(rep)
+    assert rep['max_rel_fwd'] <= TOL, rep
+    # two fp32 evaluations disagree on a handful of choices per million (pre-activations within rounding of zero)
+    assert rep['mask_flips'] <= 20e-6 * rep['decisions'], rep
+    assert rep['max_rel_grad_agreeing'] <= NORTH_STAR_TOL, rep
 
 
 def test_full_size_properties(Fn, O, dev):

@@ -166,6 +166,34 @@ def test_random_sampler_invariants():
     assert res.neg_inds.numel() <= 2 * max(1, res.pos_inds.numel()) and res.pos_gt_labels is None
 
 
+def test_cascade_refine_with_class_specific_regressor_and_background_targets():
+    """with reg_class_agnostic=False the target label of a background RoI (== num_classes) must not reach
+    regress_by_class's gather ([n, 4*num_classes] columns): background RoIs are refined by their best foreground class."""
+    import arfe_amd
+    from arfe_amd.roi_heads import cascade_refine_labels
+    nc = 5
+    head = arfe_amd.build_head(dict(
+        type='MultiRoIsBBoxHead', in_channels=16, conv_out_channels=16, fc_out_channels=8, roi_feat_size=7, num_classes=nc,
+        reg_class_agnostic=False,
+        bbox_coder=dict(type='DeltaXYWHBBoxCoder', target_means=[0., 0., 0., 0.], target_stds=[0.1, 0.1, 0.2, 0.2])))
+    g = torch.Generator().manual_seed(0)
+    n = 12
+    rois = torch.cat([torch.zeros(n, 1), torch.rand(n, 2, generator=g) * 50, 60 + torch.rand(n, 2, generator=g) * 50], 1)
+    labels = torch.tensor([0, 1, nc, nc, 4, 2, nc, 3, nc, 0, nc, 1])
+    cls_score = torch.randn(n, nc + 1, generator=g)
+    cls_score[:, nc] += 10.0                         # background is the arg-max everywhere: it must still not be chosen
+    bbox_pred = torch.randn(n, 4 * nc, generator=g) * 0.1
+    lab = cascade_refine_labels(head, labels, cls_score)
+    assert int(lab.max()) < nc and torch.equal(lab[labels != nc], labels[labels != nc])
+    assert torch.equal(lab[labels == nc], cls_score[labels == nc, :nc].argmax(1))
+    out = head.refine_bboxes(rois, lab, bbox_pred, [torch.zeros(3, dtype=torch.uint8)], [dict(img_shape=(200, 200, 3))])
+    assert out[0].shape == (n, 4) and torch.isfinite(out[0]).all()
+    with pytest.raises((RuntimeError, IndexError)):   # what the raw target labels do (the hole in the reference at HEAD)
+        head.refine_bboxes(rois, labels, bbox_pred, [torch.zeros(3, dtype=torch.uint8)], [dict(img_shape=(200, 200, 3))])
+    head.reg_class_agnostic = True                   # class-agnostic heads (every AR cascade config): labels pass through
+    assert cascade_refine_labels(head, labels, cls_score) is labels
+
+
 def test_resnet_surface():
     net = arfe_amd.build_backbone(dict(type='ResNet', depth=50, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=1,
                                        norm_cfg=dict(type='BN', requires_grad=True), norm_eval=True, style='pytorch'))

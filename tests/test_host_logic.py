@@ -244,3 +244,36 @@ def test_bench_inputs_equal_the_checkers():
     for a, b in zip(synth.synth_pyramid(1, 4, seed=7), O.synth_pyramid(1, 4, seed=7)):
         assert torch.equal(a, b)
     assert torch.equal(synth.synth_rois(2, 33, seed=5), O.synth_rois(2, 33, seed=5))
+
+
+def test_bench_refuses_to_measure_fewer_gpus_than_it_claims():
+    """`bench.py --gpus N` must never print a line for a different rank count.  Without a launcher it starts
+    its own ranks (and says so when the node has too few GPUs for RCCL); with a launcher whose WORLD_SIZE disagrees with
+    --gpus it stops before anything is measured."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'ARFE_DIST_BACKEND')}
+    # launcher present, wrong world size
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8'], env=dict(env, WORLD_SIZE='1'),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and 'WORLD_SIZE=1' in r.stderr and '"metric"' not in r.stdout
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1'], env=dict(env, WORLD_SIZE='2'),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and '"metric"' not in r.stdout
+    # no launcher: self-launch; on a node with fewer GPUs than ranks (this container has none) it refuses, loudly
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2'], env=env, capture_output=True,
+                           text=True, timeout=300)
+        assert r.returncode == 2 and 'needs 2 GPUs' in r.stderr and '"metric"' not in r.stdout
+
+
+def test_bench_cpu_share_respects_affinity_and_override(monkeypatch):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    n = bench.host_cpu_share()
+    assert 1 <= n <= len(os.sched_getaffinity(0))
+    monkeypatch.setenv('ARFE_CPU_THREADS', '3')
+    assert bench.host_cpu_share() == 3
