@@ -233,6 +233,7 @@ struct BlockQuadTable {       // pixel quads (B*h*ceil(w/4)) of each level, in w
     int first_blk[NL_ + 1];
     int64_t quads[NL_];
     int wq[NL_];
+    int nwork[NL_];           // XCD-ordered kernels: 64-quad blocks of the level with work (first_blk advances in multiples of 8)
 };
 
 // out = x + nearest(bsf) * (a + b).  Workgroup = 64 pixel quads (block-aligned per level, so the level is a function
@@ -244,7 +245,15 @@ __global__ __launch_bounds__(256) void fpn_scatter_fwd_kernel(Levels lv, BlockQu
     const int lq = threadIdx.x & 63, cw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int lvl = 0;
     while (lvl + 1 < lv.n && (int)blockIdx.x >= bt.first_blk[lvl + 1]) ++lvl;
-    const unsigned q_blk = (unsigned)((int)blockIdx.x - bt.first_blk[lvl]) * 64u;
+    // XCD-aware order (round 3): a level's workgroups start at a multiple of 8 and gridDim.x is one, so workgroup j of the
+    // level runs on XCD j % 8 whatever blockIdx.y is; it takes quad block (j % 8) * ceil(n / 8) + j / 8, i.e. each XCD walks
+    // one contiguous range of the level and the bsf rows a range shares (a level-0 row block re-reads its bsf row 4 times)
+    // are fetched by ONE L2 instead of eight (PMC: 268 MB fetched for 192).
+    const int jb = (int)blockIdx.x - bt.first_blk[lvl];
+    const int nwork = bt.nwork[lvl];
+    const int wb = (jb & 7) * ((nwork + 7) >> 3) + (jb >> 3);
+    if (wb >= nwork) return;
+    const unsigned q_blk = (unsigned)wb * 64u;
     unsigned q = q_blk + lq;
     const bool active = q < (unsigned)bt.quads[lvl];
     if (!active) q = q_blk;
@@ -1121,6 +1130,14 @@ static PixQuadTable make_pixquad_table(const Levels& lv) {
     }
     return pt;
 }
+// second-generation kernels (fpn_stream.hip)
+int32_t fpn_input_bwd_v2(const Levels& lv, const float* const* gout, const float* const* dpa, const float* const* dpb,
+                         const float* const* w1, const float* const* w2, const float* dm, const int32_t* argmax,
+                         float* const* dx, hipStream_t stream);
+
+int32_t fpn_scatter_fwd_v2(const Levels& lv, const float* const* x, const float* bsf, const float* const* a,
+                           const float* const* b, float* const* out, hipStream_t stream);
+
 template <class T>
 static bool fill_ptrs(T& dst, const float* const* src, int n) {
     for (int i = 0; i < NL_; ++i) dst.p[i] = nullptr;
@@ -1195,6 +1212,10 @@ extern "C" int32_t arfe_fpn_scatter_fwd(const arfe_pyramid_t* pyr, const float* 
     ARFE_CHECK_ARG(fill_ptrs(xp, x, lv.n) && fill_ptrs(ap, a, lv.n) && fill_ptrs(bp, b, lv.n) &&
                        fill_ptrs(op, out, lv.n) && bsf,
                    ARFE_ERR_ARG, "fpn_scatter_fwd: null pointer");
+    {
+        const int32_t done = fpn_scatter_fwd_v2(lv, x, bsf, a, b, out, as_stream(stream));      // round 3 (fpn_stream.hip)
+        if (done) return done < 0 ? done : ARFE_OK;
+    }
     BlockQuadTable bt;
     int nblk = 0;
     for (int i = 0; i <= NL_; ++i) {
@@ -1203,7 +1224,8 @@ extern "C" int32_t arfe_fpn_scatter_fwd(const arfe_pyramid_t* pyr, const float* 
             bt.wq[i] = i < lv.n ? cdiv(lv.W[i], 4) : 0;
             bt.quads[i] = i < lv.n ? (int64_t)lv.B * lv.H[i] * bt.wq[i] : 0;
             ARFE_CHECK_ARG(bt.quads[i] < (int64_t)1 << 31, ARFE_ERR_ARG, "fpn_scatter_fwd: level %d too large", i);
-            nblk += (int)cdiv64(bt.quads[i], 64);
+            bt.nwork[i] = (int)cdiv64(bt.quads[i], 64);
+            nblk += 8 * cdiv(bt.nwork[i], 8);
         }
     }
     hipLaunchKernelGGL(fpn_scatter_fwd_kernel, dim3(nblk, cdiv(lv.C, 4 * SC_CG * SC_NB)), dim3(256), 0, as_stream(stream), lv,
@@ -1284,6 +1306,10 @@ extern "C" int32_t arfe_fpn_input_bwd(const arfe_pyramid_t* pyr, const float* co
                        fill_ptrs(w1p, w1, lv.n) && fill_ptrs(w2p, w2, lv.n) && fill_ptrs(dxp, dx, lv.n) && dm &&
                        (argmax || lv.r == 0),
                    ARFE_ERR_ARG, "fpn_input_bwd: null pointer");
+    // round 3: the item-map kernel (fpn_stream.hip) takes every level it supports in ONE launch; what is left (ragged finer
+    // levels, ratios above 4) goes through the first-generation kernels below
+    const int32_t done = fpn_input_bwd_v2(lv, gout, dpre_a, dpre_b, w1, w2, dm, argmax, dx, as_stream(stream));
+    if (done < 0) return done;
     // levels with an exact power-of-two ratio to the refine level take the shift-only kernel, the rest (e.g. the
     // 13x21 top level of the 1333x800 pyramid, 25 -> 13 by a ceil) the generic one: two launches over disjoint levels
     for (int pass = 0; pass < 3; ++pass) {
@@ -1295,10 +1321,11 @@ extern "C" int32_t arfe_fpn_input_bwd(const arfe_pyramid_t* pyr, const float* co
                 const int shi = lv.sh[i];
                 // shift-only kernel: finer-or-equal levels below the refine level, coarser-or-equal ones above it
                 const bool pow2 = shi != SH_GENERAL && (i < lv.r ? shi >= 0 : shi <= 0);
-                const int mode = i >= lv.n ? -1 : (pow2 ? 0 : (i >= lv.r ? 1 : 2));
+                const int mode = (i >= lv.n || ((done >> i) & 1)) ? -1 : (pow2 ? 0 : (i >= lv.r ? 1 : 2));
                 bt.wq[i] = i < lv.n ? cdiv(lv.W[i], 4) : 0;
                 bt.quads[i] = mode == pass ? (int64_t)lv.B * lv.H[i] * bt.wq[i] : 0;
                 ARFE_CHECK_ARG(bt.quads[i] < (int64_t)1 << 31, ARFE_ERR_ARG, "fpn_input_bwd: level %d too large", i);
+                bt.nwork[i] = (int)cdiv64(bt.quads[i], 64);
                 nblk += (int)cdiv64(bt.quads[i], 64);
             }
         }
