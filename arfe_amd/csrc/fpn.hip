@@ -1135,6 +1135,8 @@ int32_t fpn_input_bwd_v2(const Levels& lv, const float* const* gout, const float
                          const float* const* w1, const float* const* w2, const float* dm, const int32_t* argmax,
                          float* const* dx, hipStream_t stream);
 
+int32_t fpn_gather_gate_v2(const Levels& lv, const float* const* x, const float* const* w1, const float* const* w2, float* m,
+                           int32_t* argmax, float* Gbuf, float* T, hipStream_t stream);
 int32_t fpn_scatter_fwd_v2(const Levels& lv, const float* const* x, const float* bsf, const float* const* a,
                            const float* const* b, float* const* out, hipStream_t stream);
 
@@ -1196,6 +1198,47 @@ extern "C" int32_t arfe_fpn_gatemap_fwd(const arfe_pyramid_t* pyr, const float* 
     hipLaunchKernelGGL(fpn_gate_mfma_kernel, dim3(tt.first_tile[lv.n]), dim3(64 * GM_WAVES), 0, st, lv, tt, xp,
                        (const float*)Wp, pre);
     ARFE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(fpn_gate_finish_kernel, dim3((unsigned)cdiv64(pre_total, 256)), dim3(256), 0, st, lv, tt, pre,
+                       pre_total, b1p, b2p, ap, bp);
+    ARFE_CHECK_LAUNCH();
+    return ARFE_OK;
+}
+
+// gather + gate maps in one call (round 3): when the pyramid is eligible the fused kernel reads x ONCE for both
+// (fpn_stream.hip); otherwise the two first-generation ops run one after the other.  Results are those of
+// arfe_fpn_gather_fwd + arfe_fpn_gatemap_fwd (m and argmax bit-identical).
+extern "C" int64_t arfe_fpn_gather_gate_workspace_bytes(const arfe_pyramid_t* pyr) {
+    const int64_t base = arfe_fpn_gatemap_workspace_bytes(pyr);
+    if (base < 0) return base;
+    const int64_t per = (int64_t)pyr->batch * pyr->channels * pyr->height[pyr->refine_level] * pyr->width[pyr->refine_level];
+    return base + (int64_t)pyr->refine_level * per * (int64_t)sizeof(float);
+}
+
+extern "C" int32_t arfe_fpn_gather_gate_fwd(const arfe_pyramid_t* pyr, const float* const* x, const float* const* w1,
+                                            const float* const* b1, const float* const* w2, const float* const* b2, float* m,
+                                            int32_t* argmax, float* const* a, float* const* b, void* workspace,
+                                            void* stream) {
+    int32_t rc = check_pyramid(pyr);
+    if (rc) return rc;
+    Levels lv = to_levels(pyr);
+    LevelPtrs xp, w1p, w2p, b1p, b2p;
+    LevelMutPtrs ap, bp;
+    ARFE_CHECK_ARG(fill_ptrs(xp, x, lv.n) && fill_ptrs(w1p, w1, lv.n) && fill_ptrs(w2p, w2, lv.n) &&
+                       fill_ptrs(b1p, b1, lv.n) && fill_ptrs(b2p, b2, lv.n) && fill_ptrs(ap, a, lv.n) &&
+                       fill_ptrs(bp, b, lv.n) && workspace && m,
+                   ARFE_ERR_ARG, "fpn_gather_gate_fwd: null pointer");
+    TileTable tt = make_tile_table(lv);
+    const int64_t pre_total = tt.px_off[lv.n];
+    float* pre = (float*)workspace;
+    float* Gbuf = (float*)((char*)workspace + arfe_fpn_gatemap_workspace_bytes(pyr));
+    hipStream_t st = as_stream(stream);
+    const int32_t done = fpn_gather_gate_v2(lv, x, w1, w2, m, argmax, Gbuf, pre, st);
+    if (done < 0) return done;
+    if (!done) {
+        rc = arfe_fpn_gather_fwd(pyr, x, m, argmax, stream);
+        if (rc) return rc;
+        return arfe_fpn_gatemap_fwd(pyr, x, w1, b1, w2, b2, a, b, workspace, stream);
+    }
     hipLaunchKernelGGL(fpn_gate_finish_kernel, dim3((unsigned)cdiv64(pre_total, 256)), dim3(256), 0, st, lv, tt, pre,
                        pre_total, b1p, b2p, ap, bp);
     ARFE_CHECK_LAUNCH();

@@ -438,6 +438,292 @@ __global__ __launch_bounds__(256) void fpn_scatter_fwd2_kernel(Levels lv, ItemTa
 #undef ARFE_SC2
 }
 
+// =========================================================================================================
+// gather + gate maps, fused (round 3): ONE read of the pyramid feeds
+//   (a) the pooled maps of the levels finer than the refine level (adaptive max over 4x4 / 2x2 windows + argmax), and
+//   (b) the 18 (gate, tap) product maps T[m][px] = sum_c W[m][c] x[c][px] of BOTH 3x3 gate convs of every level
+// (wfpn_dual_spatial.py:102-113 and :119-121).  The first-generation path read the pyramid twice (fpn_gather_fwd and
+// fpn_gate_mfma: 2 x 183 MB at the bench size).
+//   lanes     the item map with the rows of a pooling window on ADJACENT lanes (LR = log2 of the window height): the window
+//             maximum is an in-lane fold over the quad plus LR quad-permute exchanges, in the scan order of
+//             F.adaptive_max_pool2d (first maximum wins, the last NaN wins).
+//   gate conv 36 packed FMAs per (quad, channel): (acc_gate1, acc_gate2)[tap][pixel] += (w1, w2)[c][tap] * x[c][pixel] with
+//             the weight pair as a scalar operand; 72 accumulators per lane.  The workgroup's 4 waves split the channels and
+//             add their accumulators through LDS (two halves of 36) in a fixed order; T is finished (9-tap shift-add, bias,
+//             ReLU, tanh) by fpn_gate_finish_kernel as before.
+//   mean      m = (((((0 + G0) + G1) + ...) / n is a separate small kernel over the refine-sized maps (fpn_gather_mean_kernel):
+//             the levels at or above the refine level enter it straight from x through the nearest index.
+// =========================================================================================================
+#ifndef ARFE_GG_U
+#define ARFE_GG_U 1
+#endif
+#ifndef ARFE_GG_WAVES
+#define ARFE_GG_WAVES 3
+#endif
+#ifndef ARFE_GG_NW
+#define ARFE_GG_NW 4
+#endif
+constexpr int GG_NW = ARFE_GG_NW;       // waves of a workgroup = channel slices of the same 64 quads
+constexpr int GG_U = ARFE_GG_U;
+constexpr int GG_M = 18;
+
+__device__ __forceinline__ float dpp_xor1(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)); }
+__device__ __forceinline__ float dpp_xor2(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)); }
+__device__ __forceinline__ int dpp_xor1(int v) { return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true); }
+__device__ __forceinline__ int dpp_xor2(int v) { return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true); }
+
+// (value, index) of two window parts, `mine` and the partner lane's; `later` = this lane's part comes later in scan order
+__device__ __forceinline__ void pool_combine(float& v, int& i, float ov, int oi, bool later) {
+    // sequential rule: a later element replaces the running maximum iff it is greater or a NaN
+    const bool mine_wins = later ? ((v > ov) || (v != v)) : !((ov > v) || (ov != ov));
+    v = mine_wins ? v : ov;
+    i = mine_wins ? i : oi;
+}
+
+struct GGTable {
+    int first_blk[NLS + 1];
+    int nwork[NLS];
+    int items[NLS], wq[NLS];
+    int lr[NLS];               // log2 rows per lane group: 2 (4x4 windows), 1 (2x2 windows), 0 (level not pooled)
+    int64_t px_off[NLS + 1];   // prefix sum of B*h*w: offset of a level inside T
+};
+
+template <int LR, bool WIDE>
+__device__ __forceinline__ void gather_gate_level(const Levels& lv, const GGTable& tb, int lvl, int blk, int lane, int cw,
+                                                  const float* __restrict__ x, const float* w1, const float* w2,
+                                                  float* __restrict__ G, int32_t* __restrict__ argmax, float* __restrict__ T,
+                                                  float* red) {
+    const int h = lv.H[lvl], w = lv.W[lvl], wq = tb.wq[lvl];
+    const int hr = lv.H[lv.r], wr = lv.W[lv.r];
+    const Item it = item_of(LR, blk * 64, lane, tb.items[lvl], wq, h, w);
+    const int C = lv.C;
+    const unsigned plane = (unsigned)(h * w), plane_r = (unsigned)(hr * wr);
+    const unsigned off = (unsigned)it.bi * (unsigned)C * plane + (unsigned)(it.y * w + it.x0);
+    const int cpw = (C + GG_NW - 1) / GG_NW;
+    const int c_begin = cw * cpw < C ? cw * cpw : C, c_end = c_begin + cpw < C ? c_begin + cpw : C;
+    const const_fp k1g = (const_fp)(uintptr_t)w1, k2g = (const_fp)(uintptr_t)w2;
+    const int r = lane & ((1 << LR) - 1);
+    // pooled output offset (+ c * plane_r): window row y >> LR, first window column of the quad
+    const unsigned goff = (unsigned)it.bi * (unsigned)C * plane_r + (unsigned)((it.y >> LR) * wr + (it.x0 >> LR));
+    const int f0 = it.y * w + it.x0;
+
+    f32x2_t acc[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[t][e] = f32x2_t{0.f, 0.f};
+
+    // software pipeline: the reads of batch k + 1 are issued before batch k is consumed (the workgroup's 4 waves are all the
+    // waves these pixels get - 2.7 per SIMD at the bench size - so latency is hidden inside a wave, not across waves)
+    auto issue = [&](float4_u (&xv)[GG_U], int c0) {
+#pragma unroll
+        for (int u = 0; u < GG_U; ++u) {
+            const int c = c0 + u < c_end ? c0 + u : c_end - 1;
+            xv[u] = load_quad<WIDE>(x + (size_t)(c < 0 ? 0 : c) * plane + off, it);
+        }
+    };
+    auto consume = [&](const float4_u (&xv)[GG_U], int c0) {
+#pragma unroll
+        for (int u = 0; u < GG_U; ++u) {
+            const bool live = c0 + u < c_end;                       // wave-uniform; a dead slot repeats the last channel
+            const int c = live ? c0 + u : c_end - 1;
+            const const_fp k1 = k1g + c * 9, k2 = k2g + c * 9;
+            const float sc = live ? 1.f : 0.f;                      // ... and contributes nothing
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const f32x2_t us = {k1[t] * sc, k2[t] * sc};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[t][e] += us * f32x2_t{xv[u][e], xv[u][e]};
+            }
+            if constexpr (LR == 2) {
+                // 4x4 window = this quad in 4 rows (lanes 4k .. 4k+3)
+                float v = xv[u][0];
+                int i = f0;
+#pragma unroll
+                for (int e = 1; e < 4; ++e) {
+                    const bool take = (xv[u][e] > v) || (xv[u][e] != xv[u][e]);
+                    v = take ? xv[u][e] : v;
+                    i = take ? f0 + e : i;
+                }
+                pool_combine(v, i, dpp_xor1(v), dpp_xor1(i), (r & 1) != 0);
+                pool_combine(v, i, dpp_xor2(v), dpp_xor2(i), (r & 2) != 0);
+                if (r == 0 && it.active && live) {
+                    G[(size_t)c * plane_r + goff] = v;
+                    if (argmax) argmax[(size_t)c * plane_r + goff] = i;
+                }
+            } else if constexpr (LR == 1) {
+                // two 2x2 windows per quad (pixels 0,1 and 2,3) in 2 rows (lanes 2k, 2k+1)
+                const bool tA = (xv[u][1] > xv[u][0]) || (xv[u][1] != xv[u][1]);
+                const bool tB = (xv[u][3] > xv[u][2]) || (xv[u][3] != xv[u][3]);
+                float vA = tA ? xv[u][1] : xv[u][0], vB = tB ? xv[u][3] : xv[u][2];
+                int iA = tA ? f0 + 1 : f0, iB = tB ? f0 + 3 : f0 + 2;
+                pool_combine(vA, iA, dpp_xor1(vA), dpp_xor1(iA), r != 0);
+                pool_combine(vB, iB, dpp_xor1(vB), dpp_xor1(iB), r != 0);
+                if (r == 0 && it.active && live) {
+                    float* gp = G + (size_t)c * plane_r + goff;
+                    gp[0] = vA; gp[1] = vB;
+                    if (argmax) { int32_t* ap = argmax + (size_t)c * plane_r + goff; ap[0] = iA; ap[1] = iB; }
+                }
+            }
+        }
+    };
+    float4_u xa[GG_U], xb[GG_U];
+    if (c_begin < c_end) {
+        issue(xa, c_begin);
+#pragma unroll 1
+        for (int c0 = c_begin; c0 < c_end; c0 += 2 * GG_U) {
+            issue(xb, c0 + GG_U);                      // (past the end: clamped re-reads of the last channel, never consumed)
+            consume(xa, c0);
+            if (c0 + GG_U < c_end) {
+                issue(xa, c0 + 2 * GG_U);
+                consume(xb, c0 + GG_U);
+            }
+        }
+    }
+    // ---- channel quarters -> T: two halves (gate 1, gate 2) of 36 values per lane through LDS, summed wave 0..3 ----
+    float* Tb = T + tb.px_off[lvl] * GG_M + (size_t)it.bi * GG_M * plane + (size_t)(it.y * w + it.x0);
+#pragma unroll
+    for (int gate = 0; gate < 2; ++gate) {
+        if (gate) __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[((cw * 9 + t) * 4 + e) * 64 + lane] = acc[t][e][gate];
+        __syncthreads();
+        // tap t is finished by wave t % GG_NW
+#pragma unroll
+        for (int tt = 0; tt < (9 + GG_NW - 1) / GG_NW; ++tt) {
+            const int t = cw + GG_NW * tt;
+            if (t < 9) {
+                float4_u o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float sum = red[((0 * 9 + t) * 4 + e) * 64 + lane];
+#pragma unroll
+                    for (int wv = 1; wv < GG_NW; ++wv) sum += red[((wv * 9 + t) * 4 + e) * 64 + lane];
+                    o[e] = sum;
+                }
+                if (it.active) store_quad<WIDE>(Tb + (size_t)(gate * 9 + t) * plane, it, w, o);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(64 * GG_NW, ARFE_GG_WAVES) void fpn_gather_gate_kernel(Levels lv, GGTable tb, SLevelPtrs x, SLevelPtrs w1, SLevelPtrs w2,
+                                                              SLevelMutPtrs G, int32_t* __restrict__ argmax,
+                                                              float* __restrict__ T) {
+    __shared__ float red[GG_NW * 9 * 4 * 64];              // 36 KB at 4 waves: [wave][tap][pixel][lane]
+    const int lane = threadIdx.x & 63, cw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int lvl = lv.n - 1;
+    while (lvl > 0 && (int)blockIdx.x >= tb.first_blk[lvl - 1]) --lvl;
+    const int j = (int)blockIdx.x - tb.first_blk[lvl];
+    const int nwork = tb.nwork[lvl];
+    const int blk = (j & 7) * ((nwork + 7) >> 3) + (j >> 3);          // XCD-aware order, see fpn_input_bwd2_kernel
+    if (blk >= nwork) return;
+    const size_t am_off = (size_t)lvl * lv.B * lv.C * lv.H[lv.r] * lv.W[lv.r];
+    int32_t* am = argmax ? argmax + am_off : nullptr;
+    switch (tb.lr[lvl]) {
+        case 2: gather_gate_level<2, true>(lv, tb, lvl, blk, lane, cw, x.p[lvl], w1.p[lvl], w2.p[lvl], G.p[lvl], am, T, red); break;
+        case 1: gather_gate_level<1, true>(lv, tb, lvl, blk, lane, cw, x.p[lvl], w1.p[lvl], w2.p[lvl], G.p[lvl], am, T, red); break;
+        default:
+            if ((lv.W[lvl] & 3) == 0)
+                gather_gate_level<0, true>(lv, tb, lvl, blk, lane, cw, x.p[lvl], w1.p[lvl], w2.p[lvl], nullptr, nullptr, T, red);
+            else
+                gather_gate_level<0, false>(lv, tb, lvl, blk, lane, cw, x.p[lvl], w1.p[lvl], w2.p[lvl], nullptr, nullptr, T, red);
+            break;
+    }
+}
+
+// m = (((((0 + G_0) + G_1) + ...) + G_{n-1}) / n over the refine-sized maps: pooled levels from G, the others from x through
+// the nearest index (exactly the first-generation kernel's arithmetic: the result is bit-identical)
+__global__ __launch_bounds__(256) void fpn_gather_mean_kernel(Levels lv, SLevelPtrs x, SLevelPtrs G, float* __restrict__ m) {
+    // one thread per 4 consecutive pixels of a refine-level row (16-byte accesses where the row allows)
+    const int hr = lv.H[lv.r], wr = lv.W[lv.r], wqr = (wr + 3) >> 2;
+    const unsigned rows = (unsigned)(lv.B * lv.C * hr);
+    const unsigned q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= rows * (unsigned)wqr) return;
+    const unsigned row = q / (unsigned)wqr;                  // (b, c, py)
+    const int px0 = (int)(q - row * (unsigned)wqr) * 4;
+    const unsigned bc = row / (unsigned)hr;
+    const int py = (int)(row - bc * (unsigned)hr);
+    const bool full = px0 + 3 < wr;
+    const size_t o = (size_t)row * wr + px0;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < lv.n; ++i) {
+        float g[4];
+        if (i < lv.r || lv.sh[i] == 0) {
+            const float* src = (i < lv.r ? G.p[i] : x.p[i]) + o;
+            if (full) {
+                const float4_u v = *reinterpret_cast<const float4_u*>(src);
+                g[0] = v[0]; g[1] = v[1]; g[2] = v[2]; g[3] = v[3];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[e] = src[px0 + e < wr ? e : 0];
+            }
+        } else {
+            const int h = lv.H[i], w = lv.W[i];
+            const int sy = nearest_src(py, h, nearest_scale(h, hr));
+            const float xs = nearest_scale(w, wr);
+            const float* srow = x.p[i] + ((size_t)bc * h + sy) * w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = srow[nearest_src(px0 + e < wr ? px0 + e : wr - 1, w, xs)];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = acc[e] + g[e];
+    }
+    const float n = (float)lv.n;
+    if (full) {
+        const float4_u v = {acc[0] / n, acc[1] / n, acc[2] / n, acc[3] / n};
+        *reinterpret_cast<float4_u*>(m + o) = v;
+    } else {
+        for (int e = 0; e < 4 && px0 + e < wr; ++e) m[o + e] = acc[e] / n;
+    }
+}
+
+// -> 1 handled, 0 not eligible (the caller runs the two first-generation ops), < 0 error.
+// Gbuf: refine_level maps [B,C,hr,wr] (workspace); T: [18 * sum(B h w)] floats (the gate maps' product buffer).
+int32_t fpn_gather_gate_v2(const Levels& lv, const float* const* x, const float* const* w1, const float* const* w2, float* m,
+                           int32_t* argmax, float* Gbuf, float* T, hipStream_t stream) {
+    static const bool off = []() { const char* e = getenv("ARFE_FPN_V2"); return e && e[0] == '0'; }();
+    if (off) return 0;
+    if (lv.C < GG_NW) return 0;
+    GGTable tb;
+    SLevelPtrs xp, w1p, w2p, gp;
+    SLevelMutPtrs gm;
+    const int64_t per = (int64_t)lv.B * lv.C * lv.H[lv.r] * lv.W[lv.r];
+    if (per * 4 >= ((int64_t)1 << 31)) return 0;
+    int nblk = 0;
+    int64_t px = 0;
+    for (int i = 0; i < NLS; ++i) {
+        tb.nwork[i] = 0; tb.items[i] = 0; tb.wq[i] = 1; tb.lr[i] = 0; tb.px_off[i] = px;
+        xp.p[i] = w1p.p[i] = w2p.p[i] = gp.p[i] = nullptr; gm.p[i] = nullptr;
+        if (i < lv.n) px += (int64_t)lv.B * lv.H[i] * lv.W[i];
+    }
+    tb.px_off[NLS] = px;
+    for (int i = 0; i < lv.n; ++i) {
+        if ((lv.W[i] & 3) != 0 && i < lv.r) return 0;    // pooled levels need whole quads
+        if ((int64_t)lv.B * lv.C * lv.H[i] * lv.W[i] * 4 >= ((int64_t)1 << 31)) return 0;
+        if (i < lv.r && !(lv.sh[i] == 1 || lv.sh[i] == 2)) return 0;
+    }
+    for (int i = lv.n - 1; i >= 0; --i) {
+        tb.first_blk[i] = nblk;
+        xp.p[i] = x[i]; w1p.p[i] = w1[i]; w2p.p[i] = w2[i];
+        if (i < lv.r) { gm.p[i] = Gbuf + (size_t)i * per; gp.p[i] = gm.p[i]; tb.lr[i] = lv.sh[i]; }
+        tb.wq[i] = cdiv(lv.W[i], 4);
+        tb.items[i] = lv.B * lv.H[i] * tb.wq[i];
+        tb.nwork[i] = cdiv(tb.items[i], 64);
+        nblk += 8 * cdiv(tb.nwork[i], 8);
+    }
+    for (int i = lv.n; i <= NLS; ++i) tb.first_blk[i] = 0;
+    tb.first_blk[NLS] = nblk;
+    hipLaunchKernelGGL(fpn_gather_gate_kernel, dim3(nblk), dim3(64 * GG_NW), 0, stream, lv, tb, xp, w1p, w2p, gm, argmax, T);
+    if (hipGetLastError() != hipSuccess) { set_error("fpn_gather_gate launch failed"); return ARFE_ERR_LAUNCH; }
+    const int64_t mquads = (int64_t)lv.B * lv.C * lv.H[lv.r] * cdiv(lv.W[lv.r], 4);
+    hipLaunchKernelGGL(fpn_gather_mean_kernel, dim3((unsigned)cdiv64(mquads, 256)), dim3(256), 0, stream, lv, xp, gp, m);
+    if (hipGetLastError() != hipSuccess) { set_error("fpn_gather_mean launch failed"); return ARFE_ERR_LAUNCH; }
+    return 1;
+}
+
 // host mirror of nearest_src (the device form uses floorf on the same fp32 product)
 static int longest_nearest_run(int in_size, int out_size) {
     const float scale = nearest_scale(in_size, out_size);

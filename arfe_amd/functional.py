@@ -136,6 +136,27 @@ def fpn_gatemap_op(xs, w1, b1, w2, b2, refine_level=0):
     return a, b
 
 
+def fpn_gather_gate_op(xs, w1, b1, w2, b2, refine_level, want_argmax=True):
+    """-> (m, argmax, a, b): gather and both gate maps from ONE read of the pyramid (arfe_fpn_gather_gate_fwd)."""
+    hip.require_f32_cuda(*xs, *w1, *b1, *w2, *b2)
+    pyr = Pyramid.of(xs, refine_level)
+    B, C = xs[0].shape[:2]
+    hr, wr = xs[refine_level].shape[2:]
+    dev = xs[0].device
+    m = torch.empty(B, C, hr, wr, device=dev)
+    argmax = None
+    if want_argmax and refine_level > 0:
+        argmax = torch.empty(refine_level, B, C, hr, wr, dtype=torch.int32, device=dev)
+    a = [torch.empty(x.shape[0], 1, x.shape[2], x.shape[3], device=dev) for x in xs]
+    b = [torch.empty(x.shape[0], 1, x.shape[2], x.shape[3], device=dev) for x in xs]
+    ws = _ws(hip.lib().arfe_fpn_gather_gate_workspace_bytes(ctypes.byref(pyr)), dev)
+    with probe('fpn_gather_gate_fwd'):
+        check(hip.lib().arfe_fpn_gather_gate_fwd(ctypes.byref(pyr), ptr_array(xs), ptr_array(w1), ptr_array(b1), ptr_array(w2),
+                                                 ptr_array(b2), ptr(m), ptr(argmax), ptr_array(a), ptr_array(b), ptr(ws),
+                                                 stream()), "arfe_fpn_gather_gate_fwd")
+    return m, argmax, a, b
+
+
 def fpn_scatter_op(xs, bsf, a, b, refine_level):
     hip.require_f32_cuda(*xs, bsf, *a, *b)
     pyr = Pyramid.of(xs, refine_level)
@@ -257,14 +278,10 @@ class ARFPNFunction(torch.autograd.Function):
         w1, b1, w2, b2 = ([v.contiguous() for v in l] for l in (w1, b1, w2, b2))
         need_grad = any(ctx.needs_input_grad)
         dev = xs[0].device
-        # the gate maps depend only on the inputs: they stream the pyramid on the side stream while the small
-        # NonLocal contractions (which cannot fill the chip) run on the main one.  (Releasing the side stream only after
-        # the gather was measured: the gather drops from 83 to 62 us, but the gate MFMA kernel then shares the chip with the
-        # six-MFMA logit contractions, which lose 55 us - the neck forward ended 35 us later.)
-        a, b = on_side(dev, lambda: fpn_gatemap_op(xs, w1, b1, w2, b2, refine_level))
-        m, argmax = fpn_gather_op(xs, refine_level, want_argmax=need_grad)
+        # (round 2 ran the gate maps on the side stream beside gather + NonLocal: two reads of the pyramid.  The fused op
+        # reads it once, in front of the NonLocal block.)
+        m, argmax, a, b = fpn_gather_gate_op(xs, w1, b1, w2, b2, refine_level, want_argmax=need_grad)
         bsf, saved = nonlocal_fwd_op(m, wt, bt, wp, bp, wg, bg, wo, bo)
-        join_side(dev)
         outs = fpn_scatter_op(xs, bsf, a, b, refine_level)
         if _decision_tap is not None:
             _decision_tap.update(argmax=argmax, gate_a=a, gate_b=b)

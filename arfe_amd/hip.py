@@ -42,6 +42,8 @@ SIGNATURES = {
     "arfe_fpn_gather_fwd": (_i32, [_PP, _vp, _vp, _vp, _vp]),
     "arfe_fpn_gatemap_workspace_bytes": (_i64, [_PP]),
     "arfe_fpn_gatemap_fwd": (_i32, [_PP, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "arfe_fpn_gather_gate_workspace_bytes": (_i64, [_PP]),
+    "arfe_fpn_gather_gate_fwd": (_i32, [_PP, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "arfe_fpn_scatter_fwd": (_i32, [_PP, _vp, _vp, _vp, _vp, _vp, _vp]),
     "arfe_fpn_scatter_bwd": (_i32, [_PP, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "arfe_fpn_input_bwd": (_i32, [_PP, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

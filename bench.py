@@ -306,8 +306,8 @@ def main():
         conv_flop = 2.0 * 256 * 256 * 9 * R * 49
         avg_ms = sum(conv_ms) / max(len(conv_ms), 1)
         ach = conv_flop / (avg_ms * 1e-3) / 1e12 if conv_ms else 0.0
-        fpn_keys = ['fpn_gather_fwd', 'fpn_gatemap_fwd', 'fpn_scatter_fwd', 'fpn_scatter_bwd', 'fpn_input_bwd',
-                    'fpn_gate_wgrad']
+        fpn_keys = ['fpn_gather_gate_fwd', 'fpn_gather_fwd', 'fpn_gatemap_fwd', 'fpn_scatter_fwd', 'fpn_scatter_bwd',
+                    'fpn_input_bwd', 'fpn_gate_wgrad']
         fpn_ms = sum(sum(stage_probes.get(k, [])) for k in fpn_keys) / stage_steps
         hbm_gbs = ARFPN_HBM_BYTES_PER_IMG * B / (fpn_ms * 1e-3) / 1e9 if fpn_ms > 0 else 0.0
         nl_ms = (sum(stage_probes.get('nonlocal_fwd', [])) + sum(stage_probes.get('nonlocal_bwd', []))) / stage_steps

@@ -63,6 +63,15 @@ int32_t arfe_fpn_gatemap_fwd(const arfe_pyramid_t* pyr, const float* const* x, c
                              const float* const* b1, const float* const* w2, const float* const* b2,
                              float* const* a, float* const* b, void* workspace, void* stream);
 
+/* gather (:102-113) and gate maps (:119-121) from ONE read of the pyramid: same results as arfe_fpn_gather_fwd followed by
+ * arfe_fpn_gatemap_fwd (m and argmax bit-identical).  workspace: arfe_fpn_gather_gate_workspace_bytes(pyr) bytes.  Pyramids the
+ * fused kernel does not take (pooled levels whose ratio to the refine level is not 2 or 4, widths not a multiple of 4,
+ * channels not a multiple of 4) run the two separate ops inside. */
+int64_t arfe_fpn_gather_gate_workspace_bytes(const arfe_pyramid_t* pyr);
+int32_t arfe_fpn_gather_gate_fwd(const arfe_pyramid_t* pyr, const float* const* x, const float* const* w1,
+                                 const float* const* b1, const float* const* w2, const float* const* b2, float* m,
+                                 int32_t* argmax, float* const* a, float* const* b, void* workspace, void* stream);
+
 /* scatter + gate + residual (:125,135): out_i = x_i + nearest(bsf -> h_i x w_i) * (a_i + b_i). */
 int32_t arfe_fpn_scatter_fwd(const arfe_pyramid_t* pyr, const float* const* x, const float* bsf,
                              const float* const* a, const float* const* b, float* const* out, void* stream);

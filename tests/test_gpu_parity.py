@@ -80,6 +80,34 @@ def test_gatemap_matches_oracle(Fn, O, dev, shape):
         assert (a[i].cpu() > 0).eq(ra > 0).float().mean() > 0.999
 
 
+@pytest.mark.parametrize('shape,r,C', [('tiny', 2, 12), ('mid', 2, 20), ('mid', 1, 8), ('ragged', 2, 12), ('mid', 2, 6),
+                                       ('bench', 2, 8)])
+def test_gather_gate_fused_matches_oracle(Fn, O, dev, shape, r, C):
+    """arfe_fpn_gather_gate_fwd: gather and both gate maps from one read of the pyramid.  m and argmax bit-exact (the fused
+    kernel's window maximum is a lane-parallel fold that must keep adaptive_max_pool2d's first-maximum scan order), gate maps
+    within TOL; 'ragged' and C = 6 are pyramids the fused kernel refuses (the call runs the two separate ops inside), 'bench'
+    is the 1333x800 pyramid (4x4 and 2x2 windows, a generic top level)."""
+    sizes = O.PYRAMID_1333x800 if shape == 'bench' else PYRAMIDS[shape]
+    g = torch.Generator().manual_seed(11)
+    xs = [torch.randn(2, C, h, w, generator=g) for h, w in sizes]
+    xs[0][0, 1, :4, :4] = 0.25                 # a window of ties: the FIRST maximum's index must win
+    xs[1][1, 0, 2:4, 2:4] = 1.5
+    w1 = [torch.randn(1, C, 3, 3, generator=g) * 0.1 for _ in xs]
+    w2 = [torch.randn(1, C, 3, 3, generator=g) * 0.1 for _ in xs]
+    b1 = [torch.randn(1, generator=g) * 0.1 for _ in xs]
+    b2 = [torch.randn(1, generator=g) * 0.1 for _ in xs]
+    m, argmax, a, b = Fn.fpn_gather_gate_op(cu(xs, dev), cu(w1, dev), cu(b1, dev), cu(w2, dev), cu(b2, dev), r)
+    ref = O.fpn_gather(xs, r, explicit=True)
+    assert torch.equal(m.cpu(), ref)
+    hr, wr = xs[r].shape[2:]
+    for i in range(r):
+        _, idx = torch.nn.functional.adaptive_max_pool2d(xs[i], (hr, wr), return_indices=True)
+        assert torch.equal(argmax[i].cpu().long(), idx), f"argmax level {i}"
+    for i, x in enumerate(xs):
+        ra, rb = O.gate_maps(x, w1[i], b1[i], w2[i], b2[i])
+        assert relerr(a[i], ra) <= TOL and relerr(b[i], rb) <= TOL, i
+
+
 @pytest.mark.parametrize('shape', list(PYRAMIDS))
 @pytest.mark.parametrize('r', [2, 3])
 def test_scatter_matches_oracle(Fn, O, dev, shape, r):

@@ -24,6 +24,7 @@ dpa, dpb, dbsf = Fn.fpn_scatter_bwd_op(g, bsf, a, b, 2)
 MB = 91.67 * B
 print(f"gather     {t(lambda: Fn.fpn_gather_op(xs, 2)):8.1f} us   (ideal {MB/6.3e3*1e3:.0f} us @6.3TB/s for {MB:.0f} MB)")
 print(f"gatemap    {t(lambda: Fn.fpn_gatemap_op(xs, w1, b1, w2, b2, 2)):8.1f} us   ({MB:.0f} MB)")
+print(f"gath+gate  {t(lambda: Fn.fpn_gather_gate_op(xs, w1, b1, w2, b2, 2)):8.1f} us   ({MB:.0f} MB)")
 print(f"scatter    {t(lambda: Fn.fpn_scatter_op(xs, bsf, a, b, 2)):8.1f} us   ({2*MB:.0f} MB)")
 print(f"scat_bwd   {t(lambda: Fn.fpn_scatter_bwd_op(g, bsf, a, b, 2)):8.1f} us   ({2*MB:.0f} MB)")
 print(f"input_bwd  {t(lambda: Fn.fpn_input_bwd_op(g, dpa, dpb, w1, w2, dbsf, am, 2)):8.1f} us   ({2*MB:.0f} MB)")
