@@ -48,11 +48,31 @@ class SingleRoIExtractor(nn.Module):
     def map_roi_levels(self, rois, num_levels):
         return Fn.map_roi_levels_op(rois.contiguous(), num_levels, self.finest_scale)
 
+    def roi_rescale(self, rois, scale_factor):
+        """single_level.py:95-107: the box scaled about its centre (RoI bookkeeping on [R, 5], plain tensor ops)."""
+        cx = (rois[:, 1] + rois[:, 3]) * 0.5
+        cy = (rois[:, 2] + rois[:, 4]) * 0.5
+        new_w = (rois[:, 3] - rois[:, 1]) * scale_factor
+        new_h = (rois[:, 4] - rois[:, 2]) * scale_factor
+        return torch.stack((rois[:, 0], cx - new_w * 0.5, cy - new_h * 0.5, cx + new_w * 0.5, cy + new_h * 0.5), dim=-1)
+
     @force_fp32(apply_to=('feats', ), out_fp16=True)
     def forward(self, feats, rois, roi_scale_factor=None, lvl=None, replace_rois=None):
-        if roi_scale_factor is not None or lvl is not None or replace_rois is not None:
-            raise NotImplementedError("roi_scale_factor / lvl / replace_rois are unused by the AR-RFF path")
-        return self._extract(feats, [rois])
+        """single_level.py:109-152.  The fork's three options (unused by the AR configs) are host-side RoI bookkeeping in front
+        of the same RoIAlign launch: `replace_rois` - other boxes decide the levels; `lvl` - the levels shifted up or down and
+        clamped; `roi_scale_factor` - the boxes rescaled about their centres AFTER the levels were taken from the originals."""
+        if roi_scale_factor is None and lvl is None and replace_rois is None:
+            return self._extract(feats, [rois])
+        feats = list(feats)[:self.num_inputs]
+        rois = rois.float().contiguous()
+        num_levels = len(feats)
+        src = replace_rois.float().contiguous() if replace_rois is not None else rois
+        levels = self.map_roi_levels(src, num_levels)            # (one level: all zeros, the reference's shortcut)
+        if lvl is not None:
+            levels = (levels + lvl).clamp(min=0, max=num_levels - 1).long()
+        if roi_scale_factor is not None:
+            rois = self.roi_rescale(rois, roi_scale_factor).contiguous()
+        return self._extract(feats, [rois], [levels.contiguous()])
 
     @force_fp32(apply_to=('feats', ), out_fp16=True)
     def extract_sets(self, feats, roi_sets):

@@ -828,6 +828,41 @@ def test_cascade_roi_head_stages_match_oracle(O, dev):
     assert len(outs) == 6 and outs[0].shape == (12, 81) and outs[5].shape == (12, 320)
 
 
+def test_extractor_fork_options_match_oracle(O, dev):
+    """single_level.py:110-141, the fork's extra arguments: `replace_rois` (levels from other boxes), `lvl` (levels shifted
+    and clamped) and `roi_scale_factor` (boxes rescaled after the levels were chosen), each against the oracle's RoIAlign on
+    the level the reference would pick."""
+    import arfe_amd
+    C = 6
+    g = torch.Generator().manual_seed(23)
+    feats = [torch.randn(2, C, h, w, generator=g) for h, w in PYRAMIDS['mid']]
+    strides = [4, 8, 16, 32, 64]
+    ext = arfe_amd.build_roi_extractor(dict(type='SingleRoIExtractor', roi_layer=dict(type='RoIAlign', out_size=7, sample_num=0),
+                                            out_channels=C, featmap_strides=strides))
+    rois = O.synth_rois(2, 20, img_w=384, img_h=256, seed=4)
+    other = O.synth_rois(2, 20, img_w=384, img_h=256, seed=5)
+    fd = [f.to(dev) for f in feats]
+
+    def ref(boxes, levels):
+        out = torch.zeros(boxes.shape[0], C, 7, 7)
+        for i in range(5):
+            idx = (levels == i).nonzero(as_tuple=True)[0]
+            if idx.numel():
+                out[idx] = O.roi_align_fwd(feats[i], boxes[idx], 1.0 / strides[i])
+        return out
+
+    lv = O.map_roi_levels(rois, 5)
+    for kw, boxes, levels in (
+            (dict(lvl=1), rois, (lv + 1).clamp(0, 4)),
+            (dict(lvl=-2), rois, (lv - 2).clamp(0, 4)),
+            (dict(replace_rois=other.to(dev)), rois, O.map_roi_levels(other, 5)),
+            (dict(roi_scale_factor=1.5), ext.roi_rescale(rois, 1.5), lv),
+            (dict(roi_scale_factor=0.7, lvl=1, replace_rois=other.to(dev)), ext.roi_rescale(rois, 0.7),
+             (O.map_roi_levels(other, 5) + 1).clamp(0, 4))):
+        got = ext(fd, rois.to(dev), **kw)
+        assert relerr(got, ref(boxes, levels)) <= 1e-5, kw
+
+
 def test_empty_roi_set_flows_through_extractor_and_head(dev):
     """R = 0 (an image batch without proposals) must give empty outputs and zero gradients, not a crash."""
     import arfe_amd
@@ -958,6 +993,82 @@ def test_fp16_mode_through_plugin_surface(O, dev):
     assert relerr(bbox_feats, d['bbox_feats']) <= FP16_FWD_TOL
     assert relerr(cls, d['cls']) <= FP16_FWD_TOL and relerr(reg, d['reg']) <= FP16_FWD_TOL
     check_fp16_grads(d, [x.grad for x in xs], grads)
+
+
+def test_cascade_roi_head_in_fp16_mode_matches_oracle(O, dev):
+    """BASELINE configs[4] at test size: `[FPN, WFPNDualSpatial]` + CascadeRoIHead (3 AR-RFF stages) under wrap_fp16_model
+    (mmdet/core/fp16/hooks.py:86-105; cascade_roi_head.py:126-149 per stage) against the oracle's fp16-mode restatement,
+    every stage with its own head weights and shifted boxes: forward within a half ulp of the storage contract, gradients of
+    all three heads and of the shared neck / FPN in L2."""
+    import arfe_amd
+    from conftest import fp16_fixture
+    d, xs_cpu, P = fp16_fixture()
+    C = 8
+    fpn = arfe_amd.build_neck(dict(type='FPN', in_channels=[4, 6, 8, 10], out_channels=C, num_outs=5))
+    neck = arfe_amd.build_neck(dict(type='WFPNDualSpatial', in_channels=C, num_levels=5))
+    ext = dict(type='SingleRoIExtractor', roi_layer=dict(type='RoIAlign', out_size=7, sample_num=0), out_channels=C,
+               featmap_strides=[4, 8, 16, 32, 64])
+    head = dict(type='MultiRoIsBBoxHead', in_channels=C, conv_out_channels=C, fc_out_channels=24, roi_feat_size=7,
+                num_classes=80, reg_class_agnostic=True)
+    rh = arfe_amd.build_head(dict(type='CascadeRoIHead', num_stages=3, stage_loss_weights=[1, 0.5, 0.25],
+                                  bbox_roi_extractor=ext, bbox_head=head))
+    fpn.load_state_dict({k: v.detach() for k, v in P['fpn.'].items()})
+    neck.load_state_dict({k: v.detach() for k, v in P['neck.'].items()})
+    g = torch.Generator().manual_seed(17)
+    stage_params = []
+    for st in range(3):        # half-representable weights per stage (the fixture's for stage 0, perturbed copies after it)
+        sp = {k: (v.detach() + 0.03 * st * torch.randn(v.shape, generator=g)).half().float() for k, v in P['head.'].items()}
+        if st == 0:
+            sp = {k: v.detach().clone() for k, v in P['head.'].items()}
+        # class-agnostic regression (every AR cascade config): fc_reg has 4 outputs
+        sp['fc_reg.weight'] = sp['fc_reg.weight'][:4].clone()
+        sp['fc_reg.bias'] = sp['fc_reg.bias'][:4].clone()
+        rh.bbox_head[st].load_state_dict(sp)
+        stage_params.append({k: v.clone().requires_grad_(True) for k, v in sp.items()})
+    mods = [fpn.to(dev), neck.to(dev), rh.to(dev)]
+    for m in mods:
+        arfe_amd.wrap_fp16_model(m)
+    assert all(p.dtype == torch.float16 for m in mods for p in m.parameters())
+    xs = [x.detach().to(dev).requires_grad_(True) for x in xs_cpu]
+    feats = neck(fpn(xs))
+    rois = d['rois']
+    # oracle: shared trunk once, one head per stage
+    xo = [x.detach().clone().requires_grad_(True) for x in xs_cpu]
+    Pf = {k: v.detach().clone().requires_grad_(True) for k, v in P['fpn.'].items()}
+    Pn = {k: v.detach().clone().requires_grad_(True) for k, v in P['neck.'].items()}
+    o_pyr = [O.half_store(t) for t in O.fpn_forward([O.half_store(x) for x in xo], Pf, 5)]
+    o_feats = [O.half_store(t) for t in O.arfpn_forward(o_pyr, Pn, 2)]
+    HALF_ULP = 2e-3
+    loss, o_loss = 0., 0.
+    for st in range(3):
+        r = rois.clone()
+        r[:, 1:] += 2.0 * st
+        res = rh._bbox_forward(st, feats, r.to(dev))
+        assert res['cls_score'].dtype == torch.float16 and res['bbox_pred'].dtype == torch.float16
+        o_bbox = O.half_store(O.roi_extract3(o_feats, r))
+        o_cls, o_reg = O.rff_head(o_bbox, stage_params[st])
+        o_cls, o_reg = O.half_store(o_cls), O.half_store(o_reg)
+        assert relerr(res['bbox_feats'], o_bbox) <= HALF_ULP, st
+        assert relerr(res['cls_score'], o_cls) <= HALF_ULP and relerr(res['bbox_pred'], o_reg) <= HALF_ULP, st
+        c1 = torch.randn(o_cls.shape, generator=g).half().float()
+        c2 = torch.randn(o_reg.shape, generator=g).half().float()
+        loss = loss + (res['cls_score'] * c1.to(dev)).sum() + (res['bbox_pred'] * c2.to(dev)).sum()
+        o_loss = o_loss + (o_cls * c1).sum() + (o_reg * c2).sum()
+    loss.backward()
+    o_loss.backward()
+    for i in range(4):
+        assert relerr_l2(xs[i].grad, xo[i].grad) <= 8e-3, i
+    for st in range(3):
+        for k, v in rh.bbox_head[st].named_parameters():
+            assert v.grad.dtype == torch.float16
+            assert relerr_l2(v.grad, stage_params[st][k].grad) <= 8e-3, (st, k)
+    for k, v in neck.named_parameters():
+        if k == 'refine.phi.conv.bias':
+            continue
+        if Pn[k].grad is None:          # the gate conv of a level no RoI maps to: no gradient in the reference, none / zero here
+            assert v.grad is None or float(v.grad.float().abs().max()) == 0.0, k
+            continue
+        assert relerr_l2(v.grad, Pn[k].grad) <= 8e-3, k
 
 
 def test_fp16_mode_dtype_mismatch_raises_like_the_reference(dev):

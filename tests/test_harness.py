@@ -241,7 +241,7 @@ def test_detectors_build_from_the_reference_configs():
     assert c.model.type == 'CascadeRCNN' and c.model.roi_head.num_stages == 3 and len(c.train_cfg.rcnn) == 3
 
 
-def _small_detector(kind, dev):
+def _small_detector(kind, dev, depth=50):
     """Faster / Cascade R-CNN R50 + [FPN, AR-FPN] + AR-RFF with the AR configs' settings at a reduced RoI / proposal budget."""
     rcnn = dict(assigner=dict(type='MaxIoUAssigner', pos_iou_thr=0.5, neg_iou_thr=0.5, min_pos_iou=0.5, match_low_quality=False,
                               ignore_iof_thr=-1),
@@ -268,7 +268,7 @@ def _small_detector(kind, dev):
         roi_head = dict(type='CascadeRoIHead', num_stages=3, stage_loss_weights=[1, 0.5, 0.25], bbox_roi_extractor=ext,
                         bbox_head=[dict(head, reg_class_agnostic=True, bbox_coder=dict(head['bbox_coder'], target_stds=s)) for s in stds])
     model = dict(type=kind, pretrained=None,
-                 backbone=dict(type='ResNet', depth=50, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=1,
+                 backbone=dict(type='ResNet', depth=depth, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=1,
                                norm_cfg=dict(type='BN', requires_grad=True), norm_eval=True, style='pytorch'),
                  neck=[dict(type='FPN', in_channels=[256, 512, 1024, 2048], out_channels=256, num_outs=5),
                        dict(type='WFPNDualSpatial', in_channels=256, num_levels=5)],
@@ -285,12 +285,13 @@ def _small_detector(kind, dev):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('kind', ['FasterRCNN', 'CascadeRCNN'])
-def test_detector_forward_train_end_to_end(kind):
-    """BASELINE configs #2/#3 (Faster R-CNN) and #5's architecture (Cascade R-CNN, 3 AR-RFF stages): synthetic COCO-shaped
-    batch -> losses -> backward, with FPN, AR-FPN, the 3-set RoIAlign and the AR-RFF head on the HIP library."""
+@pytest.mark.parametrize('kind,depth', [('FasterRCNN', 50), ('CascadeRCNN', 50), ('CascadeRCNN', 101)])
+def test_detector_forward_train_end_to_end(kind, depth):
+    """BASELINE configs #2/#3 (Faster R-CNN R50) and #5's architecture (Cascade R-CNN R101, 3 AR-RFF stages): synthetic
+    COCO-shaped batch -> losses -> backward, with FPN, AR-FPN, the 3-set RoIAlign and the AR-RFF head on the HIP library."""
     dev = torch.device('cuda:0')
-    det = _small_detector(kind, dev)
+    det = _small_detector(kind, dev, depth)
+    assert len(det.backbone.layer3) == (23 if depth == 101 else 6)
     img, metas, gt_bboxes, gt_labels = D.synthetic_batch(batch=2, height=256, width=384, max_gt=8, seed=1, device=dev)
     losses = det.forward_train(img, metas, gt_bboxes, gt_labels)
     want = {'loss_rpn_cls', 'loss_rpn_bbox'} | ({'loss_cls', 'acc', 'loss_bbox'} if kind == 'FasterRCNN' else
