@@ -214,7 +214,13 @@ static inline bool launch_conv_stage_once(int R, int C, const unsigned short* wp
         *rc = ARFE_ERR_LAUNCH;
         return true;
     }
+    // probe switches (skip the epilogue / MFMA phase / staging: wrong results on purpose) exist only in a build with
+    // -DARFE_PROBES (tools/probe/build_variant.sh); the shipped library ignores ARFE_CONV_DBG
+#ifdef ARFE_PROBES
     static const int dbg = []() { const char* e = getenv("ARFE_CONV_DBG"); return e ? atoi(e) : 0; }();
+#else
+    constexpr int dbg = 0;
+#endif
     ConvStageDims d{C, N, C, cdiv(N, CS_BN), dbg};      // a ragged last tile: clamped loads, columns >= N are never stored
     hipLaunchKernelGGL((conv3x3_stage_once_kernel<EPI>), dim3(d.tiles_n, cdiv(C, XL_BM)), dim3(512), CS_LDS_BYTES, stream, d,
                        wplanes, x, roi_stride, epi);

@@ -282,7 +282,13 @@ static inline bool launch_conv_wgrad_stage_once(int R, int C, const float* x, in
         return true;
     }
     WgradStageDims d;
+    // probe switches (skip the epilogue / MFMA phase / staging: wrong results on purpose) exist only in a build with
+    // -DARFE_PROBES (tools/probe/build_variant.sh); the shipped library ignores ARFE_CONV_DBG
+#ifdef ARFE_PROBES
     static const int dbg = []() { const char* e = getenv("ARFE_CONV_DBG"); return e ? atoi(e) : 0; }();
+#else
+    constexpr int dbg = 0;
+#endif
     d.R = R; d.C = C; d.rows_total = R * 7; d.tiles_ci = C / WS_CI; d.dbg = dbg;
     const int tiles = (C / WS_CO) * d.tiles_ci;
     int nslices = 256 / tiles;

@@ -961,7 +961,10 @@ __global__ __launch_bounds__(256) void fpn_input_bwd_kernel(Levels lv, BlockQuad
 //   (3 entries per thread), and the MFMA operands are then fetched k-major from the padded images.  One workgroup =
 //   256 pixels of one image x 256 channels (4 waves x 2 channel tiles); partial sums are added atomically (18 per channel).
 // =========================================================================================================
-constexpr int GW_PX = 32, GW_STAGES = 8, GW_LD = 36, GW_CH = 256;
+#ifndef ARFE_GW_STAGES
+#define ARFE_GW_STAGES 8
+#endif
+constexpr int GW_PX = 32, GW_STAGES = ARFE_GW_STAGES, GW_LD = 36, GW_CH = 256;
 __global__ void fpn_gate_wgrad_zero_kernel(int C, int n, LevelMutPtrs dw1, LevelMutPtrs db1, LevelMutPtrs dw2, LevelMutPtrs db2) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int per = 9 * C;

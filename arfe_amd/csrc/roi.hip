@@ -119,7 +119,15 @@ __device__ __forceinline__ bool axis_tap(float c, int n, int& lo, int& hi, float
 // RoIs (of all sets) are binned per 16x16 feature tile; one workgroup owns (tile, 32 channels), walks its RoI
 // list and WRITES every element of dfeats exactly once (no memset, no atomics on the feature maps).
 constexpr int RT = 16;          // tile edge
-constexpr int RB_CC = 16;       // channels per workgroup
+#ifndef ARFE_RB_NB
+#define ARFE_RB_NB 2
+#endif
+#ifndef ARFE_RB_CC
+#define ARFE_RB_CC 32
+#endif
+constexpr int RB_CC = ARFE_RB_CC;   // channels per workgroup (round 3: 32, a wave owns 8; the per-RoI bookkeeping - list entries, header,
+                                    // weight staging, two barriers - is paid once per workgroup and was 2/3 of the kernel's time at 16)
+constexpr int RB_CPW = RB_CC / 4;   // channels per wave
 constexpr int RB_MAXSETS = 4;
 
 struct RoiSets {
@@ -519,7 +527,7 @@ __global__ __launch_bounds__(256) void roialign_fwd_sep_kernel(RoiLevels L, RoiS
 // contracts its 4 channels on the matrix pipe:
 //   C:  T[(c,ph)][x] = sum_pw G[c][ph][pw] wx[pw][x]      D:  dX_c[y][x] += sum_ph wy[y][ph] T_c[ph][x]
 // (separable form of the bilinear scatter; every feature element is written once, no atomics unless a long list is cut).
-constexpr int RB_NB = 4;
+constexpr int RB_NB = ARFE_RB_NB;
 // Slicing a long RoI list over several workgroups (grid.z; the slices add atomically into pre-zeroed tiles) is OFF by default:
 // the lists of the bench (up to 201 RoIs on a coarse tile, dispatched first) finish inside the kernel's run anyway, while every
 // extra grid.z layer is 12 k workgroups that start only to exit - measured 434 us (32, 4) / 467 us (150, 2) / 391 us (off)
@@ -528,7 +536,17 @@ constexpr int RB_SEGS_DEF = 1;    // slices of a long RoI list
 constexpr int RB_SEG_MIN_DEF = 1 << 30;   // lists up to this length stay in one workgroup (plain stores)
 struct RbSeg { int segs, seg_min; };
 static RbSeg rb_seg() {
-    static const RbSeg v = []() { RbSeg r{RB_SEGS_DEF, RB_SEG_MIN_DEF}; const char* e = getenv("ARFE_RB_SEG"); if (e) sscanf(e, "%d,%d", &r.seg_min, &r.segs); return r; }();
+    static const RbSeg v = []() {
+        RbSeg r{RB_SEGS_DEF, RB_SEG_MIN_DEF};
+        const char* e = getenv("ARFE_RB_SEG");
+        if (e && sscanf(e, "%d,%d", &r.seg_min, &r.segs) == 2) {
+            r.segs = r.segs < 1 ? 1 : (r.segs > 16 ? 16 : r.segs);      // grid.z of the tile kernel: never 0, never huge
+            r.seg_min = r.seg_min < 1 ? 1 : r.seg_min;
+        } else {
+            r = RbSeg{RB_SEGS_DEF, RB_SEG_MIN_DEF};
+        }
+        return r;
+    }();
     return v;
 }
 constexpr int RB_GS = 60, RB_TS = 20;
@@ -557,7 +575,7 @@ __global__ __launch_bounds__(256) void roi_zero_sliced_tiles_kernel(RoiLevels L,
     (void)ntiles;
 }
 
-static_assert(RB_CC == 16 && RT == 16, "the MFMA tiles are 16x16: a wave owns 4 of the 16 channels, a tile is 16x16 pixels");
+static_assert(RB_CC % 8 == 0 && RT == 16, "the MFMA tiles are 16x16: a wave owns RB_CC / 4 channels (pairs in the C phase), a tile is 16x16 pixels");
 __global__ __launch_bounds__(256) void roialign_bwd_tiles_kernel(RoiLevels L, RoiSets S, RoiTileTable T, int P, int sample_num,
                                                                  const float* __restrict__ gout, int64_t g_roi_stride,
                                                                  const int* __restrict__ offsets, const int* __restrict__ list,
@@ -598,9 +616,9 @@ __global__ __launch_bounds__(256) void roialign_bwd_tiles_kernel(RoiLevels L, Ro
     // D tile layout: lane l holds rows 4*(l/16)+r, r = 0..3, of column l%16.
     typedef float f32x4_t __attribute__((ext_vector_type(4)));
     const int lane = tid & 63, wv = tid >> 6, l15 = lane & 15, lq = lane >> 4;
-    f32x4_t acc[4];
+    f32x4_t acc[RB_CPW];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) acc[c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < RB_CPW; ++c) acc[c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     // pad lanes of the k = 8 contractions (bin 7) are never written by the staging below: zero them once
     for (int i = tid; i < RB_NB * RT; i += 256) { wy_s[i / RT][rb_wrow(i % RT) + 7] = 0.f; wx_s[i / RT][rb_wrow(i % RT) + 7] = 0.f; }
     for (int i = tid; i < RB_NB * RB_CC * 7; i += 256) G_s[i / (RB_CC * 7)][(i / 7) % RB_CC][(i % 7) * 8 + 7] = 0.f;
@@ -680,8 +698,8 @@ __global__ __launch_bounds__(256) void roialign_bwd_tiles_kernel(RoiLevels L, Ro
         // ---- C then D per RoI (per wave, its own 4 channels: no workgroup barrier, T_s rows are private to the wave) ----
         for (int j = 0; j < nb; ++j) {
 #pragma unroll
-            for (int pr = 0; pr < 2; ++pr) {
-                const int cl = wv * 4 + pr * 2 + (l15 >> 3), ph = l15 & 7;      // A row l15 -> (channel, bin)
+            for (int pr = 0; pr < RB_CPW / 2; ++pr) {
+                const int cl = wv * RB_CPW + pr * 2 + (l15 >> 3), ph = l15 & 7;      // A row l15 -> (channel, bin)
                 f32x4_t t = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
@@ -690,14 +708,14 @@ __global__ __launch_bounds__(256) void roialign_bwd_tiles_kernel(RoiLevels L, Ro
                     t = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, t, 0, 0, 0);
                 }
                 // rows 4*lq + r of the M tile = (channel 4v + 2pr + (lq >> 1), bin 4*(lq & 1) + r), column l15
-                *reinterpret_cast<f32x4_t*>(&T_s[wv * 4 + pr * 2 + (lq >> 1)][l15][(4 * (lq & 1)) ^ ((l15 & 8) >> 1)]) = t;
+                *reinterpret_cast<f32x4_t*>(&T_s[wv * RB_CPW + pr * 2 + (lq >> 1)][l15][(4 * (lq & 1)) ^ ((l15 & 8) >> 1)]) = t;
             }
             const float a0 = wy_s[j][rb_wrow(l15) + lq], a1 = wy_s[j][rb_wrow(l15) + 4 + lq];
             __builtin_amdgcn_s_waitcnt(0xc07f);     // lgkmcnt(0): this wave's T rows have landed
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float b0 = T_s[wv * 4 + c][l15][lq ^ ((l15 & 8) >> 1)], b1 = T_s[wv * 4 + c][l15][(4 + lq) ^ ((l15 & 8) >> 1)];
+            for (int c = 0; c < RB_CPW; ++c) {
+                const float b0 = T_s[wv * RB_CPW + c][l15][lq ^ ((l15 & 8) >> 1)], b1 = T_s[wv * RB_CPW + c][l15][(4 + lq) ^ ((l15 & 8) >> 1)];
                 acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[c], 0, 0, 0);
                 acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[c], 0, 0, 0);
             }
@@ -711,8 +729,8 @@ __global__ __launch_bounds__(256) void roialign_bwd_tiles_kernel(RoiLevels L, Ro
         for (int i = 1; i < ARFE_MAX_LEVELS; ++i) if (i == lvl) d = L.dfeat[i];
         const int ox = tx * RT + l15;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int cc = wv * 4 + c;
+        for (int c = 0; c < RB_CPW; ++c) {
+            const int cc = wv * RB_CPW + c;
             if (cc >= ncc || ox >= W) continue;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
