@@ -42,6 +42,12 @@ int32_t zero_buffers(const ZeroList& z, hipStream_t stream) {
     return ARFE_OK;
 }
 
+// operand precision of the dense contractions, PER THREAD (the autograd engine runs the backward on its own thread: the host
+// wrappers set the mode around every call they make): 0 = fp32 operands (bf16x3 / bf16x6 split), 1 = half operands
+static thread_local int g_operand_precision = 0;
+bool gemm_half_operands() { return g_operand_precision == 1; }
+void set_operand_precision(int mode) { g_operand_precision = mode == 1 ? 1 : 0; }
+
 bool gemm_use_f32() {
     // process-level switch, read once (a function-local static is initialised under the C++11 guard, so the main and
     // the autograd thread may both arrive first): ARFE_GEMM_F32=1 -> exact-fp32 MFMA
@@ -125,5 +131,11 @@ extern "C" int32_t arfe_cast_f32_to_f16(int64_t n, const float* src, void* dst, 
     return ARFE_OK;
 }
 
+extern "C" int32_t arfe_set_operand_precision(int32_t mode) {
+    if (mode != 0 && mode != 1) { arfe::set_error("set_operand_precision: mode %d (0 = fp32 operands, 1 = half operands)", mode); return ARFE_ERR_ARG; }
+    arfe::set_operand_precision(mode);
+    return ARFE_OK;
+}
+extern "C" int32_t arfe_get_operand_precision(void) { return arfe::gemm_half_operands() ? 1 : 0; }
 extern "C" const char* arfe_last_error(void) { return arfe::g_err; }
 extern "C" int32_t arfe_abi_version(void) { return ARFE_ABI_VERSION; }

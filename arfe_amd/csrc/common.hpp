@@ -121,6 +121,8 @@ int32_t zero_buffers(const ZeroList& z, hipStream_t stream);
 // dwp[tap][co][ci] -> dw[co][ci][tap] (gemm_ops.hip)
 int32_t conv3x3_unpermute_dw(int C, const float* dwp, float* dw, hipStream_t stream);
 bool gemm_use_f32();
+bool gemm_half_operands();
+void set_operand_precision(int mode);
 
 // Function attributes (the opt-in to >64 KB of dynamic LDS) and small constant blocks belong to ONE device: a process
 // that drives several GPUs must repeat them per device.  DeviceOnce is a flag per device ordinal; two threads racing

@@ -25,7 +25,9 @@ constexpr int CS_LDS_BYTES = (2 * 2 * CS_A_IMG + 2 * 2 * CS_B_IMG) * 2;     // 2
 
 struct ConvStageDims { int M, N, C, tiles_n, dbg; };   // dbg: probe switches (ARFE_CONV_DBG), 0 in production
 
-template <class EPI>
+// PREC == 1 (half-operand mode, see gemm_bf16x3.hpp): wplanes is ONE plane of IEEE halves, the activations are converted to
+// half on their way into LDS, one v_mfma_f32_16x16x32_f16 per block.
+template <class EPI, int PREC = 0>
 __global__ __launch_bounds__(512, 2) void conv3x3_stage_once_kernel(ConvStageDims d, const unsigned short* __restrict__ wplanes,
                                                                     const float* __restrict__ x, int64_t roi_stride, EPI epi) {
     extern __shared__ __attribute__((aligned(16))) unsigned short cs_lds[];
@@ -79,7 +81,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stage_once_kernel(ConvStageDim
         for (int i = 0; i < 2; ++i) {
             const int dst = (i * 8 + wave) * 64 * 8;            // wave-uniform element offset of the 1-KB piece
             __builtin_amdgcn_global_load_lds(base + a_src[i], (lds_ptr_t)(img_a(buf, 0) + dst), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(base + plane + a_src[i], (lds_ptr_t)(img_a(buf, 1) + dst), 16, 0, 0);
+            if constexpr (PREC == 0)
+                __builtin_amdgcn_global_load_lds(base + plane + a_src[i], (lds_ptr_t)(img_a(buf, 1) + dst), 16, 0, 0);
         }
     };
     auto fetch_b = [&](int slice) {
@@ -94,10 +97,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stage_once_kernel(ConvStageDim
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             bf16x8 hi, lo;
-            split8(rb[i], hi, lo);
+            if constexpr (PREC == 1) { hi = cvt8_f16(rb[i]); lo = hi; }
+            else split8(rb[i], hi, lo);
             if (b_on) {
                 *reinterpret_cast<bf16x8*>(img_b(buf, 0) + b_row * CS_BLD + 8 * b_oct[i]) = hi;
-                *reinterpret_cast<bf16x8*>(img_b(buf, 1) + b_row * CS_BLD + 8 * b_oct[i]) = lo;
+                if constexpr (PREC == 0) *reinterpret_cast<bf16x8*>(img_b(buf, 1) + b_row * CS_BLD + 8 * b_oct[i]) = lo;
             }
         }
     };
@@ -128,28 +132,37 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stage_once_kernel(ConvStageDim
         for (int t = 0; t < 4; ++t) {
             const int off = (wm * 64 + t * 16 + l15) * XS_LD + frag_oct;
             ah[t] = *reinterpret_cast<const bf16x8*>(img_a(abuf, 0) + off);
-            al[t] = *reinterpret_cast<const bf16x8*>(img_a(abuf, 1) + off);
+            if constexpr (PREC == 0) al[t] = *reinterpret_cast<const bf16x8*>(img_a(abuf, 1) + off);
+            else al[t] = ah[t];
         }
         bf16x8 bh[2], bl[2];
         {
             const int off = ((vm[0] >> tap) & 1u) ? b_base[0] + sh : zero_off;
             bh[0] = *reinterpret_cast<const bf16x8*>(img_b(bbuf, 0) + off);
-            bl[0] = *reinterpret_cast<const bf16x8*>(img_b(bbuf, 1) + off);
+            if constexpr (PREC == 0) bl[0] = *reinterpret_cast<const bf16x8*>(img_b(bbuf, 1) + off);
+            else bl[0] = bh[0];
         }
 #pragma unroll
         for (int j = 0; j < 7; ++j) {
             if (j + 1 < 7) {
                 const int off = ((vm[j + 1] >> tap) & 1u) ? b_base[j + 1] + sh : zero_off;
                 bh[(j + 1) & 1] = *reinterpret_cast<const bf16x8*>(img_b(bbuf, 0) + off);
-                bl[(j + 1) & 1] = *reinterpret_cast<const bf16x8*>(img_b(bbuf, 1) + off);
+                if constexpr (PREC == 0) bl[(j + 1) & 1] = *reinterpret_cast<const bf16x8*>(img_b(bbuf, 1) + off);
+                else bl[(j + 1) & 1] = bh[(j + 1) & 1];
             }
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (PREC == 1) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j & 1], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < 4; ++i)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah[i]), __builtin_bit_cast(f16x8, bh[j & 1]), acc[i][j], 0, 0, 0);
+            } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j & 1], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j & 1], acc[i][j], 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j & 1], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j & 1], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j & 1], acc[i][j], 0, 0, 0);
+            }
         }
     };
 
@@ -198,22 +211,31 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stage_once_kernel(ConvStageDim
         }
 }
 
+template <class EPI, int PREC>
+static inline void launch_conv_stage_once_prec(const ConvStageDims& d, const unsigned short* wplanes, const float* x,
+                                               int64_t roi_stride, EPI epi, hipStream_t stream, int32_t* rc) {
+    static DeviceOnce attr;           // per instantiation and per device
+    if (!attr.run([]() { return hipFuncSetAttribute((const void*)conv3x3_stage_once_kernel<EPI, PREC>,
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, CS_LDS_BYTES) == hipSuccess; })) {
+        set_error("conv3x3: cannot reserve %d bytes of LDS", CS_LDS_BYTES);
+        *rc = ARFE_ERR_LAUNCH;
+        return;
+    }
+    hipLaunchKernelGGL((conv3x3_stage_once_kernel<EPI, PREC>), dim3(d.tiles_n, cdiv(d.C, XL_BM)), dim3(512), CS_LDS_BYTES, stream,
+                       d, wplanes, x, roi_stride, epi);
+    if (hipGetLastError() != hipSuccess) { set_error("conv3x3 stage-once launch failed"); *rc = ARFE_ERR_LAUNCH; }
+}
+
 // -> true when the stage-once kernel ran (C a multiple of 32, at least one full tile of pixels; ARFE_CONV_STAGE_ONCE=0
-// switches it off), false to use the generic GEMM
+// switches it off), false to use the generic GEMM.  wplanes: bf16 (hi | lo) planes; wplane_f16: the same matrix as one plane
+// of halves (half-operand mode)
 template <class EPI>
-static inline bool launch_conv_stage_once(int R, int C, const unsigned short* wplanes, const float* x, int64_t roi_stride,
-                                          EPI epi, hipStream_t stream, int32_t* rc) {
+static inline bool launch_conv_stage_once(int R, int C, const unsigned short* wplanes, const unsigned short* wplane_f16,
+                                          const float* x, int64_t roi_stride, EPI epi, hipStream_t stream, int32_t* rc) {
     static const char* sw = getenv("ARFE_CONV_STAGE_ONCE");
     *rc = ARFE_OK;
     const int N = R * 49;
     if ((sw && sw[0] == '0') || gemm_use_f32() || N < CS_BN || C % 32 != 0 || C < 64) return false;
-    static DeviceOnce attr;           // per instantiation and per device
-    if (!attr.run([]() { return hipFuncSetAttribute((const void*)conv3x3_stage_once_kernel<EPI>,
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, CS_LDS_BYTES) == hipSuccess; })) {
-        set_error("conv3x3: cannot reserve %d bytes of LDS", CS_LDS_BYTES);
-        *rc = ARFE_ERR_LAUNCH;
-        return true;
-    }
     // probe switches (skip the epilogue / MFMA phase / staging: wrong results on purpose) exist only in a build with
     // -DARFE_PROBES (tools/probe/build_variant.sh); the shipped library ignores ARFE_CONV_DBG
 #ifdef ARFE_PROBES
@@ -222,9 +244,8 @@ static inline bool launch_conv_stage_once(int R, int C, const unsigned short* wp
     constexpr int dbg = 0;
 #endif
     ConvStageDims d{C, N, C, cdiv(N, CS_BN), dbg};      // a ragged last tile: clamped loads, columns >= N are never stored
-    hipLaunchKernelGGL((conv3x3_stage_once_kernel<EPI>), dim3(d.tiles_n, cdiv(C, XL_BM)), dim3(512), CS_LDS_BYTES, stream, d,
-                       wplanes, x, roi_stride, epi);
-    if (hipGetLastError() != hipSuccess) { set_error("conv3x3 stage-once launch failed"); *rc = ARFE_ERR_LAUNCH; }
+    if (gemm_half_operands()) launch_conv_stage_once_prec<EPI, 1>(d, wplane_f16, x, roi_stride, epi, stream, rc);
+    else launch_conv_stage_once_prec<EPI, 0>(d, wplanes, x, roi_stride, epi, stream, rc);
     return true;
 }
 

@@ -30,6 +30,8 @@ constexpr int WS_LDS_BYTES = (2 * WS_BUF + WS_ZERO) * 2;
 
 struct WgradStageDims { int R, C, rows_total, rows_per_slice, tiles_ci, dbg; };   // dbg: probe switches (ARFE_CONV_DBG)
 
+// PREC == 1: half-operand mode (gemm_bf16x3.hpp) - operands converted to half, one f16 MFMA per block, "lo" images unused
+template <int PREC>
 __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_stage_once_kernel(WgradStageDims d, const float* __restrict__ x,
                                                                           int64_t x_roi_stride, const float* __restrict__ dy,
                                                                           int64_t dy_roi_stride, float* __restrict__ dwp,
@@ -119,16 +121,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_stage_once_kernel(WgradS
     };
     auto stash = [&](int buf) {
         bf16x8 hi, lo;
-        split8(ra, hi, lo);
+        if constexpr (PREC == 1) { hi = cvt8_f16(ra); lo = hi; }
+        else split8(ra, hi, lo);
         *reinterpret_cast<bf16x8*>(img_a(buf, 0) + a_off) = hi;
-        *reinterpret_cast<bf16x8*>(img_a(buf, 1) + a_off) = lo;
+        if constexpr (PREC == 0) *reinterpret_cast<bf16x8*>(img_a(buf, 1) + a_off) = lo;
         if (b_on) {
             // three column-shifted copies: slot px of copy dx holds x[px + dx] (0 where px + dx leaves the row; slot 7 = 0).
             // The split is element-wise, so the row is split ONCE and the packed bf16 words are shifted (v_alignbit):
             // copy -1 = {0, e0..e5, 0}, copy +1 = {e1..e6, 0, 0}.
-            split8(rb, hi, lo);
+            if constexpr (PREC == 1) { hi = cvt8_f16(rb); lo = hi; }
+            else split8(rb, hi, lo);
             *reinterpret_cast<bf16x8*>(img_b(buf, 1, 0) + b_off) = hi;
-            *reinterpret_cast<bf16x8*>(img_b(buf, 1, 1) + b_off) = lo;
+            if constexpr (PREC == 0) *reinterpret_cast<bf16x8*>(img_b(buf, 1, 1) + b_off) = lo;
             auto shifted = [&](const bf16x8& v, bf16x8& m1, bf16x8& p1) {
                 const u32x4 w = __builtin_bit_cast(u32x4, v);
                 const unsigned t1 = __builtin_amdgcn_alignbit(w[1], w[0], 16), t2 = __builtin_amdgcn_alignbit(w[2], w[1], 16),
@@ -139,11 +143,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_stage_once_kernel(WgradS
             };
             bf16x8 hm, hp, lm, lp;
             shifted(hi, hm, hp);
-            shifted(lo, lm, lp);
             *reinterpret_cast<bf16x8*>(img_b(buf, 0, 0) + b_off) = hm;
-            *reinterpret_cast<bf16x8*>(img_b(buf, 0, 1) + b_off) = lm;
             *reinterpret_cast<bf16x8*>(img_b(buf, 2, 0) + b_off) = hp;
-            *reinterpret_cast<bf16x8*>(img_b(buf, 2, 1) + b_off) = lp;
+            if constexpr (PREC == 0) {
+                shifted(lo, lm, lp);
+                *reinterpret_cast<bf16x8*>(img_b(buf, 0, 1) + b_off) = lm;
+                *reinterpret_cast<bf16x8*>(img_b(buf, 2, 1) + b_off) = lp;
+            }
         }
     };
     // ---- fragment geometry ----
@@ -158,7 +164,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_stage_once_kernel(WgradS
         for (int i = 0; i < 2; ++i) {
             const int off = (wm * 32 + i * 16 + l15) * WS_A_LD + a_frag;
             ah[i] = *reinterpret_cast<const bf16x8*>(img_a(buf, 0) + off);
-            al[i] = *reinterpret_cast<const bf16x8*>(img_a(buf, 1) + off);
+            if constexpr (PREC == 0) al[i] = *reinterpret_cast<const bf16x8*>(img_a(buf, 1) + off);
+            else al[i] = ah[i];
         }
         // B fragments of tap t + 1 are read before the twelve MFMAs of tap t are issued (register double buffer)
         bf16x8 bh[2][2], bl[2][2];
@@ -171,7 +178,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_stage_once_kernel(WgradS
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 bh[slot][j] = *reinterpret_cast<const bf16x8*>(p + j * 16 * WS_B_LD);
-                bl[slot][j] = *reinterpret_cast<const bf16x8*>(p + WS_B_IMG + j * 16 * WS_B_LD);
+                if constexpr (PREC == 0) bl[slot][j] = *reinterpret_cast<const bf16x8*>(p + WS_B_IMG + j * 16 * WS_B_LD);
+                else bl[slot][j] = bh[slot][j];
             }
         };
         read_b(0, 0);
@@ -179,21 +187,30 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_stage_once_kernel(WgradS
         for (int t = 0; t < 9; ++t) {
             if (t + 1 < 9) read_b(t + 1, (t + 1) & 1);
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (PREC == 1) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[t & 1][j], acc[t][i][j], 0, 0, 0);
+                    for (int j = 0; j < 2; ++j)
+                        acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah[i]),
+                                                                              __builtin_bit_cast(f16x8, bh[t & 1][j]), acc[t][i][j], 0, 0, 0);
+            } else {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[t & 1][j], acc[t][i][j], 0, 0, 0);
+                    for (int j = 0; j < 2; ++j)
+                        acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[t & 1][j], acc[t][i][j], 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[t & 1][j], acc[t][i][j], 0, 0, 0);
+                    for (int j = 0; j < 2; ++j)
+                        acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[t & 1][j], acc[t][i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[t & 1][j], acc[t][i][j], 0, 0, 0);
+            }
         }
     };
 
@@ -275,7 +292,9 @@ static inline bool launch_conv_wgrad_stage_once(int R, int C, const float* x, in
     *rc = ARFE_OK;
     if ((sw && sw[0] == '0') || gemm_use_f32() || C % WS_CO != 0 || R < 64) return false;
     static DeviceOnce attr;
-    if (!attr.run([]() { return hipFuncSetAttribute((const void*)conv3x3_wgrad_stage_once_kernel,
+    if (!attr.run([]() { return hipFuncSetAttribute((const void*)conv3x3_wgrad_stage_once_kernel<0>,
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES) == hipSuccess &&
+                                hipFuncSetAttribute((const void*)conv3x3_wgrad_stage_once_kernel<1>,
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES) == hipSuccess; })) {
         set_error("conv3x3 wgrad: cannot reserve %d bytes of LDS", WS_LDS_BYTES);
         *rc = ARFE_ERR_LAUNCH;
@@ -295,8 +314,12 @@ static inline bool launch_conv_wgrad_stage_once(int R, int C, const float* x, in
     if (nslices < 1) nslices = 1;
     d.rows_per_slice = ((cdiv(d.rows_total, nslices) + 3) / 4) * 4;
     nslices = cdiv(d.rows_total, d.rows_per_slice);
-    hipLaunchKernelGGL(conv3x3_wgrad_stage_once_kernel, dim3(nslices, tiles), dim3(512), WS_LDS_BYTES, stream, d, x, x_roi_stride,
-                       dy, dy_roi_stride, dwp, db);
+    if (gemm_half_operands())
+        hipLaunchKernelGGL(conv3x3_wgrad_stage_once_kernel<1>, dim3(nslices, tiles), dim3(512), WS_LDS_BYTES, stream, d, x,
+                           x_roi_stride, dy, dy_roi_stride, dwp, db);
+    else
+        hipLaunchKernelGGL(conv3x3_wgrad_stage_once_kernel<0>, dim3(nslices, tiles), dim3(512), WS_LDS_BYTES, stream, d, x,
+                           x_roi_stride, dy, dy_roi_stride, dwp, db);
     if (hipGetLastError() != hipSuccess) { set_error("conv3x3 wgrad stage-once launch failed"); *rc = ARFE_ERR_LAUNCH; return true; }
     hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(cdiv(9 * C * C / 4, 256)), dim3(256), 0, stream, (const float*)dwp, nslices, C, dw);
     if (hipGetLastError() != hipSuccess) { set_error("conv3x3 wgrad reduce launch failed"); *rc = ARFE_ERR_LAUNCH; }

@@ -82,6 +82,55 @@ __device__ __forceinline__ void stage8(const float (&v)[8], bf16x8& hi, bf16x8& 
     else split8(v, hi, lo);
 }
 
+// ---- half-operand mode (PREC == 1; round 3) ---------------------------------------------------------------------------
+// The reference's fp16 mode (mmdet/core/fp16/hooks.py:86-105) runs its contractions on half operands.  Here the operands are
+// then converted to IEEE half on their way into LDS (exact for values that were stored as half, and the same rounding the
+// reference applies to intermediates it keeps in half) and every product is ONE v_mfma_f32_*_f16 with fp32 accumulation
+// instead of the three (six) bf16 MFMAs of the fp32-grade split: a third (sixth) of the matrix-pipe work, one LDS image per
+// operand instead of two.  The kernels keep their layout; the "lo" images are simply not written or read.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bf16x8 cvt8_f16(const float (&v)[8]) {
+    u32x4 h;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f32x2 x = {v[2 * j], v[2 * j + 1]};
+        h[j] = __builtin_bit_cast(unsigned, __builtin_convertvector(x, f16x2));      // v_cvt_pk_f16_f32... (RNE)
+    }
+    return __builtin_bit_cast(bf16x8, h);
+}
+// pre-split words (bf16 hi | bf16 lo, see presplit_word) back to the value, then to half
+__device__ __forceinline__ bf16x8 cvt8_f16_presplit(const float (&v)[8]) {
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const unsigned w = __float_as_uint(v[j]);
+        f[j] = __uint_as_float(w & 0xffff0000u) + __uint_as_float(w << 16);
+    }
+    return cvt8_f16(f);
+}
+template <int PREC, class L>
+__device__ __forceinline__ void stage8p(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+    if constexpr (PREC == 1) {
+        if constexpr (is_presplit<L>::value) hi = cvt8_f16_presplit(v);
+        else hi = cvt8_f16(v);
+        lo = hi;
+    } else {
+        stage8<L>(v, hi, lo);
+    }
+}
+template <int PREC>
+__device__ __forceinline__ f32x16 mma32p(bf16x8 ah, bf16x8 al, bf16x8 bh, bf16x8 bl, f32x16 c) {
+    if constexpr (PREC == 1) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, bh), c, 0, 0, 0);
+    } else {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+    }
+}
+bool gemm_half_operands();           // per-thread mode, arfe_set_operand_precision (api.hip)
+
 // Pipeline (round 2): two LDS buffers (2 x 32 KB, dynamic) and ONE barrier per K-step, as in the 256-wide kernels below:
 // iteration s splits + stores step s+1 into the other buffer, re-issues the global loads of step s+2 into the registers
 // just freed, then runs the 24 MFMAs of step s.  The first form (one buffer: loads -> MFMAs -> barrier -> split/store ->
@@ -89,7 +138,7 @@ __device__ __forceinline__ void stage8(const float (&v)[8], bf16x8& hi, bf16x8& 
 constexpr int XM_BUF = 4 * GEMM_BM * XS_LD;                 // bf16 elements per buffer: A_hi A_lo B_hi B_lo
 constexpr int XM_LDS_BYTES = 2 * XM_BUF * 2;                // 65 536
 
-template <class LA, class LB, class EPI>
+template <class LA, class LB, class EPI, int PREC = 0>
 __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmDims d, LA la, LB lb, EPI epi) {
     extern __shared__ __attribute__((aligned(16))) unsigned short xm_lds[];
     auto img = [&](int buf, int which) -> unsigned short* { return xm_lds + (size_t)buf * XM_BUF + which * (GEMM_BM * XS_LD); };
@@ -190,18 +239,18 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmDims d, LA la, 
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             bf16x8 hi, lo;
-            stage8<LA>(ra[i], hi, lo);
+            stage8p<PREC, LA>(ra[i], hi, lo);
             *reinterpret_cast<bf16x8*>(img(buf, 0) + a_off[i]) = hi;
-            *reinterpret_cast<bf16x8*>(img(buf, 1) + a_off[i]) = lo;
+            if constexpr (PREC == 0) *reinterpret_cast<bf16x8*>(img(buf, 1) + a_off[i]) = lo;
         }
     };
     auto stash_b = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             bf16x8 hi, lo;
-            stage8<LB>(rb[i], hi, lo);
+            stage8p<PREC, LB>(rb[i], hi, lo);
             *reinterpret_cast<bf16x8*>(img(buf, 2) + b_off[i]) = hi;
-            *reinterpret_cast<bf16x8*>(img(buf, 3) + b_off[i]) = lo;
+            if constexpr (PREC == 0) *reinterpret_cast<bf16x8*>(img(buf, 3) + b_off[i]) = lo;
         }
     };
     const int kh = lane >> 5, l31 = lane & 31;
@@ -213,18 +262,16 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmDims d, LA la, 
             const int ar = wm * 64 + t * 32 + l31, br = wn * 64 + t * 32 + l31;
             const int ko = 8 * (((kk >> 3) + kh) ^ fsw);
             ah[t] = *reinterpret_cast<const bf16x8*>(img(buf, 0) + ar * XS_LD + ko);
-            al[t] = *reinterpret_cast<const bf16x8*>(img(buf, 1) + ar * XS_LD + ko);
             bh[t] = *reinterpret_cast<const bf16x8*>(img(buf, 2) + br * XS_LD + ko);
-            bl[t] = *reinterpret_cast<const bf16x8*>(img(buf, 3) + br * XS_LD + ko);
+            if constexpr (PREC == 0) {
+                al[t] = *reinterpret_cast<const bf16x8*>(img(buf, 1) + ar * XS_LD + ko);
+                bl[t] = *reinterpret_cast<const bf16x8*>(img(buf, 3) + br * XS_LD + ko);
+            } else { al[t] = ah[t]; bl[t] = bh[t]; }
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-            }
+            for (int j = 0; j < 2; ++j) acc[i][j] = mma32p<PREC>(ah[i], al[i], bh[j], bl[j], acc[i][j]);
     };
 
     if (s_begin < s_end) {
@@ -472,7 +519,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x6_kernel(GemmDims d, LA la, 
 constexpr int XL_BM = 256, XL_BN = 256;
 constexpr int XL_LDS_BYTES = 2 * 2 * (XL_BM + XL_BN) * XS_LD * 2;      // 131 072 (swizzled 64-byte rows, see xs_swz)
 
-template <class LA, class LB, class EPI>
+template <class LA, class LB, class EPI, int PREC = 0>
 __global__ __launch_bounds__(512, 2) void gemm_bf16x3_large_kernel(GemmDims d, LA la, LB lb, EPI epi) {
     extern __shared__ __attribute__((aligned(16))) unsigned short xl_lds[];
     // buffer b: A_hi [256][40] | A_lo | B_hi | B_lo
@@ -601,18 +648,18 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_large_kernel(GemmDims d, L
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             bf16x8 hi, lo;
-            stage8<LA>(ra[i], hi, lo);
+            stage8p<PREC, LA>(ra[i], hi, lo);
             *reinterpret_cast<bf16x8*>(img(buf, 0) + a_off[i]) = hi;
-            *reinterpret_cast<bf16x8*>(img(buf, 1) + a_off[i]) = lo;
+            if constexpr (PREC == 0) *reinterpret_cast<bf16x8*>(img(buf, 1) + a_off[i]) = lo;
         }
     };
     auto stash_b = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             bf16x8 hi, lo;
-            stage8<LB>(rb[i], hi, lo);
+            stage8p<PREC, LB>(rb[i], hi, lo);
             *reinterpret_cast<bf16x8*>(img(buf, 2) + b_off[i]) = hi;
-            *reinterpret_cast<bf16x8*>(img(buf, 3) + b_off[i]) = lo;
+            if constexpr (PREC == 0) *reinterpret_cast<bf16x8*>(img(buf, 3) + b_off[i]) = lo;
         }
     };
     const int kh = lane >> 5, l31 = lane & 31;
@@ -623,22 +670,20 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_large_kernel(GemmDims d, L
         for (int t = 0; t < 4; ++t) {
             const int ar = wm * 128 + t * 32 + l31;
             ah[t] = *reinterpret_cast<const bf16x8*>(img(buf, 0) + ar * XS_LD + 8 * (((kk >> 3) + kh) ^ fsw));
-            al[t] = *reinterpret_cast<const bf16x8*>(img(buf, 1) + ar * XS_LD + 8 * (((kk >> 3) + kh) ^ fsw));
+            if constexpr (PREC == 0) al[t] = *reinterpret_cast<const bf16x8*>(img(buf, 1) + ar * XS_LD + 8 * (((kk >> 3) + kh) ^ fsw));
+            else al[t] = ah[t];
         }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int br = wn * 64 + t * 32 + l31;
             bh[t] = *reinterpret_cast<const bf16x8*>(img(buf, 2) + br * XS_LD + 8 * (((kk >> 3) + kh) ^ fsw));
-            bl[t] = *reinterpret_cast<const bf16x8*>(img(buf, 3) + br * XS_LD + 8 * (((kk >> 3) + kh) ^ fsw));
+            if constexpr (PREC == 0) bl[t] = *reinterpret_cast<const bf16x8*>(img(buf, 3) + br * XS_LD + 8 * (((kk >> 3) + kh) ^ fsw));
+            else bl[t] = bh[t];
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-            }
+            for (int j = 0; j < 2; ++j) acc[i][j] = mma32p<PREC>(ah[i], al[i], bh[j], bl[j], acc[i][j]);
     };
 
     if (s_begin < s_end) {
@@ -755,7 +800,7 @@ constexpr int XN_BUF = 2 * (XL_BM + XN_BN) * XS_LD;                 // bf16 elem
 constexpr int XN_LDS_BYTES = 2 * XN_BUF * 2;                        // 122 880
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <class LA, class LB, class EPI>
+template <class LA, class LB, class EPI, int PREC = 0>
 __global__ __launch_bounds__(512, 2) void gemm_bf16x3_n224_kernel(GemmDims d, LA la, LB lb, EPI epi) {
     extern __shared__ __attribute__((aligned(16))) unsigned short xn_lds[];
     auto img_a = [&](int buf, int lo) -> unsigned short* { return xn_lds + (size_t)buf * XN_BUF + lo * (XL_BM * XS_LD); };
@@ -837,17 +882,17 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_n224_kernel(GemmDims d, LA
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             bf16x8 hi, lo;
-            stage8<LA>(ra[i], hi, lo);
+            stage8p<PREC, LA>(ra[i], hi, lo);
             *reinterpret_cast<bf16x8*>(img_a(buf, 0) + a_off[i]) = hi;
-            *reinterpret_cast<bf16x8*>(img_a(buf, 1) + a_off[i]) = lo;
+            if constexpr (PREC == 0) *reinterpret_cast<bf16x8*>(img_a(buf, 1) + a_off[i]) = lo;
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             bf16x8 hi, lo;
-            stage8<LB>(rb[i], hi, lo);
+            stage8p<PREC, LB>(rb[i], hi, lo);
             if (b_ok[i]) {
                 *reinterpret_cast<bf16x8*>(img_b(buf, 0) + b_off[i]) = hi;
-                *reinterpret_cast<bf16x8*>(img_b(buf, 1) + b_off[i]) = lo;
+                if constexpr (PREC == 0) *reinterpret_cast<bf16x8*>(img_b(buf, 1) + b_off[i]) = lo;
             }
         }
     };
@@ -859,7 +904,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_n224_kernel(GemmDims d, LA
         for (int t = 0; t < 4; ++t) {
             const int off = (wm * 64 + t * 16 + l15) * XS_LD + frag_oct;
             ah[t] = *reinterpret_cast<const bf16x8*>(img_a(buf, 0) + off);
-            al[t] = *reinterpret_cast<const bf16x8*>(img_a(buf, 1) + off);
+            if constexpr (PREC == 0) al[t] = *reinterpret_cast<const bf16x8*>(img_a(buf, 1) + off);
+            else al[t] = ah[t];
         }
         // B fragments are double-buffered in registers: the two reads of column block j + 1 are issued before the twelve
         // MFMAs of block j, so the wave never sits at lgkmcnt between blocks (the compiler's own schedule read block
@@ -868,22 +914,30 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_n224_kernel(GemmDims d, LA
         {
             const int off = (wn * 112 + l15) * XS_LD + frag_oct;
             bh[0] = *reinterpret_cast<const bf16x8*>(img_b(buf, 0) + off);
-            bl[0] = *reinterpret_cast<const bf16x8*>(img_b(buf, 1) + off);
+            if constexpr (PREC == 0) bl[0] = *reinterpret_cast<const bf16x8*>(img_b(buf, 1) + off);
+            else bl[0] = bh[0];
         }
 #pragma unroll
         for (int j = 0; j < 7; ++j) {
             if (j + 1 < 7) {
                 const int off = (wn * 112 + (j + 1) * 16 + l15) * XS_LD + frag_oct;
                 bh[(j + 1) & 1] = *reinterpret_cast<const bf16x8*>(img_b(buf, 0) + off);
-                bl[(j + 1) & 1] = *reinterpret_cast<const bf16x8*>(img_b(buf, 1) + off);
+                if constexpr (PREC == 0) bl[(j + 1) & 1] = *reinterpret_cast<const bf16x8*>(img_b(buf, 1) + off);
+                else bl[(j + 1) & 1] = bh[(j + 1) & 1];
             }
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (PREC == 1) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j & 1], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < 4; ++i)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah[i]), __builtin_bit_cast(f16x8, bh[j & 1]), acc[i][j], 0, 0, 0);
+            } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j & 1], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j & 1], acc[i][j], 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j & 1], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j & 1], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j & 1], acc[i][j], 0, 0, 0);
+            }
         }
     };
 
@@ -988,16 +1042,15 @@ static inline bool plan_large_tile(int M, int N, int batch, int ksteps, int* spl
     return true;
 }
 
-template <class LA, class LB, class EPI>
-static inline int32_t launch_gemm_auto(int M, int N, int K, int kb_count, int batch, int splitk, LA la, LB lb, EPI epi,
-                                       hipStream_t stream, bool exact = false, bool kb_inner = false,
-                                       const GemmDims* zvar = nullptr) {
+template <int PREC, class LA, class LB, class EPI>
+static inline int32_t launch_gemm_prec(int M, int N, int K, int kb_count, int batch, int splitk, LA la, LB lb, EPI epi,
+                                       hipStream_t stream, bool exact, bool kb_inner, const GemmDims* zvar) {
     if constexpr (is_presplit<LA>::value) {
         // in fp32 mode the re-laid matrix holds plain floats (see conv_w_permute_kernel)
         if (gemm_use_f32())
             return launch_gemm(M, N, K, kb_count, batch, splitk, static_cast<const typename LA::Plain&>(la), lb, epi, stream,
                                kb_inner);
-        if (exact) {
+        if (exact && PREC == 0) {
             set_error("gemm: pre-split operands are not available on the bf16x6 path");
             return ARFE_ERR_ARG;
         }
@@ -1005,7 +1058,7 @@ static inline int32_t launch_gemm_auto(int M, int N, int K, int kb_count, int ba
         if (gemm_use_f32()) return launch_gemm(M, N, K, kb_count, batch, splitk, la, lb, epi, stream, kb_inner);
     }
     if (M <= 0 || N <= 0 || batch <= 0) return ARFE_OK;
-    if constexpr (!is_presplit<LA>::value) if (exact) {        // fp32-grade products from six bf16 MFMAs (see gemm_bf16x6_kernel)
+    if constexpr (!is_presplit<LA>::value && PREC == 0) if (exact) {        // fp32-grade products from six bf16 MFMAs (see gemm_bf16x6_kernel)
         GemmDims d6;
         d6.M = M; d6.N = N; d6.K = K; d6.kb_count = kb_count < 1 ? 1 : kb_count;
         d6.kb_inner = kb_inner ? 1 : 0;
@@ -1049,13 +1102,13 @@ static inline int32_t launch_gemm_auto(int M, int N, int K, int kb_count, int ba
             d.splitk = splitk;
             d.tiles_m = cdiv(M, XL_BM); d.tiles_n = N / XN_BN;
             static DeviceOnce attr224;     // per instantiation and per device
-            if (!attr224.run([]() { return hipFuncSetAttribute((const void*)gemm_bf16x3_n224_kernel<LA, LB, EPI>,
+            if (!attr224.run([]() { return hipFuncSetAttribute((const void*)gemm_bf16x3_n224_kernel<LA, LB, EPI, PREC>,
                                                                hipFuncAttributeMaxDynamicSharedMemorySize, XN_LDS_BYTES) == hipSuccess; })) {
                 set_error("gemm: cannot reserve %d bytes of LDS", XN_LDS_BYTES);
                 return ARFE_ERR_LAUNCH;
             }
             dim3 grid(d.tiles_m * d.tiles_n, splitk, batch);
-            hipLaunchKernelGGL((gemm_bf16x3_n224_kernel<LA, LB, EPI>), grid, dim3(512), XN_LDS_BYTES, stream, d, la, lb, epi);
+            hipLaunchKernelGGL((gemm_bf16x3_n224_kernel<LA, LB, EPI, PREC>), grid, dim3(512), XN_LDS_BYTES, stream, d, la, lb, epi);
             ARFE_CHECK_LAUNCH();
             return ARFE_OK;
         }
@@ -1080,13 +1133,13 @@ static inline int32_t launch_gemm_auto(int M, int N, int K, int kb_count, int ba
         }
         d.tiles_m = cdiv(M, XL_BM); d.tiles_n = cdiv(N, XL_BN);
         static DeviceOnce attr_set;        // per instantiation and per device: opt in to the full 160 KB of LDS once
-        if (!attr_set.run([]() { return hipFuncSetAttribute((const void*)gemm_bf16x3_large_kernel<LA, LB, EPI>,
+        if (!attr_set.run([]() { return hipFuncSetAttribute((const void*)gemm_bf16x3_large_kernel<LA, LB, EPI, PREC>,
                                                             hipFuncAttributeMaxDynamicSharedMemorySize, XL_LDS_BYTES) == hipSuccess; })) {
             set_error("gemm: cannot reserve %d bytes of LDS", XL_LDS_BYTES);
             return ARFE_ERR_LAUNCH;
         }
         dim3 grid(d.tiles_m * d.tiles_n, splitk, batch);
-        hipLaunchKernelGGL((gemm_bf16x3_large_kernel<LA, LB, EPI>), grid, dim3(512), XL_LDS_BYTES, stream, d, la, lb, epi);
+        hipLaunchKernelGGL((gemm_bf16x3_large_kernel<LA, LB, EPI, PREC>), grid, dim3(512), XL_LDS_BYTES, stream, d, la, lb, epi);
         ARFE_CHECK_LAUNCH();
         return ARFE_OK;
     }
@@ -1094,14 +1147,26 @@ static inline int32_t launch_gemm_auto(int M, int N, int K, int kb_count, int ba
     d.tiles_m = cdiv(M, GEMM_BM); d.tiles_n = cdiv(N, GEMM_BN);
     dim3 grid(d.tiles_m * d.tiles_n, splitk, batch);
     static DeviceOnce attr_mid;        // per instantiation and per device
-    if (!attr_mid.run([]() { return hipFuncSetAttribute((const void*)gemm_bf16x3_kernel<LA, LB, EPI>,
+    if (!attr_mid.run([]() { return hipFuncSetAttribute((const void*)gemm_bf16x3_kernel<LA, LB, EPI, PREC>,
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, XM_LDS_BYTES) == hipSuccess; })) {
         set_error("gemm: cannot reserve %d bytes of LDS", XM_LDS_BYTES);
         return ARFE_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL((gemm_bf16x3_kernel<LA, LB, EPI>), grid, dim3(256), XM_LDS_BYTES, stream, d, la, lb, epi);
+    hipLaunchKernelGGL((gemm_bf16x3_kernel<LA, LB, EPI, PREC>), grid, dim3(256), XM_LDS_BYTES, stream, d, la, lb, epi);
     ARFE_CHECK_LAUNCH();
     return ARFE_OK;
+}
+
+// half-operand mode (arfe_set_operand_precision(1), the reference's fp16 mode): the same tiles and planner, one f16 MFMA per
+// product; `exact` (the six-MFMA fp32-grade split of the softmax logits) has no meaning there - the reference's logits are
+// half products too
+template <class LA, class LB, class EPI>
+static inline int32_t launch_gemm_auto(int M, int N, int K, int kb_count, int batch, int splitk, LA la, LB lb, EPI epi,
+                                       hipStream_t stream, bool exact = false, bool kb_inner = false,
+                                       const GemmDims* zvar = nullptr) {
+    if (gemm_half_operands() && !gemm_use_f32())
+        return launch_gemm_prec<1>(M, N, K, kb_count, batch, splitk, la, lb, epi, stream, exact, kb_inner, zvar);
+    return launch_gemm_prec<0>(M, N, K, kb_count, batch, splitk, la, lb, epi, stream, exact, kb_inner, zvar);
 }
 
 static inline int gemm_bk() { return gemm_use_f32() ? GEMM_BK : XB_BK; }

@@ -172,8 +172,10 @@ struct WgradB {        // B(n=ci, k') for tap z: x[r*roi_stride + ci*49 + (py+dy
 // presplit: the elements are stored as (bf16 hi << 16 | bf16 lo) words for LoadSplitK (bf16x3 mode), else as floats
 // planes (bf16x3 mode): the same two matrices once more as bf16 PLANES - ph = [hi plane 9*C*C | lo plane 9*C*C] of wp,
 // pd likewise of wd - the form the stage-once conv kernel copies to LDS by LDS-DMA
+// fh / fd: the same two matrices as ONE plane of IEEE halves each (half-operand mode of the stage-once conv kernel)
 __global__ void conv_w_permute_kernel(const float* __restrict__ w, float* __restrict__ wp, float* __restrict__ wd, int C,
-                                      int presplit, unsigned short* __restrict__ ph, unsigned short* __restrict__ pd) {
+                                      int presplit, unsigned short* __restrict__ ph, unsigned short* __restrict__ pd,
+                                      unsigned short* __restrict__ fh, unsigned short* __restrict__ fd) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     int total = C * C * 9;
     if (i >= total) return;
@@ -181,6 +183,8 @@ __global__ void conv_w_permute_kernel(const float* __restrict__ w, float* __rest
     int a = rem / C, b = rem - a * C;
     float f = w[((int64_t)a * C + b) * 9 + tap];           // wp[tap][co=a][ci=b]
     float g = w[((int64_t)b * C + a) * 9 + (8 - tap)];     // wd[tap][ci=a][co=b]
+    fh[i] = __builtin_bit_cast(unsigned short, (_Float16)f);
+    fd[i] = __builtin_bit_cast(unsigned short, (_Float16)g);
     if (presplit) {
         const unsigned fw = presplit_word(f), gw = presplit_word(g);
         ph[i] = (unsigned short)(fw >> 16); ph[total + i] = (unsigned short)(fw & 0xffffu);
@@ -631,8 +635,8 @@ extern "C" int32_t arfe_linear_bwd(int32_t R, int32_t in_f, int32_t out_f, const
 // =========================================================================================================
 extern "C" int64_t arfe_conv3x3_packed_bytes(int32_t C) {
     // wp[tap][co][ci] followed by wd[tap][ci][co] (flipped/transposed for the data gradient), then the same two matrices
-    // as bf16 (hi plane | lo plane) for the LDS-DMA staging of the stage-once kernels
-    return (int64_t)4 * 9 * C * C * sizeof(float);
+    // as bf16 (hi plane | lo plane) for the LDS-DMA staging of the stage-once kernels, then once more as planes of halves
+    return (int64_t)5 * 9 * C * C * sizeof(float);
 }
 extern "C" int64_t arfe_conv3x3_workspace_bytes(int32_t C) {
     // permuted weight-gradient accumulator of the generic path, or the per-slice slabs of the stage-once kernel
@@ -648,8 +652,10 @@ extern "C" int32_t arfe_conv3x3_pack_weights(int32_t C, const float* w, void* pa
     int total = 9 * C * C;
     unsigned short* ph = (unsigned short*)(wd + (size_t)9 * C * C);
     unsigned short* pd = ph + (size_t)2 * 9 * C * C;
+    unsigned short* fh = pd + (size_t)2 * 9 * C * C;
+    unsigned short* fd = fh + (size_t)9 * C * C;
     hipLaunchKernelGGL(conv_w_permute_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), w, wp, wd, C,
-                       gemm_use_f32() ? 0 : 1, ph, pd);
+                       gemm_use_f32() ? 0 : 1, ph, pd, fh, fd);
     ARFE_CHECK_LAUNCH();
     return ARFE_OK;
 }
@@ -667,7 +673,8 @@ extern "C" int32_t arfe_conv3x3_fwd(int32_t R, int32_t C, const float* x, int64_
     {
         int32_t rc_so;
         const unsigned short* ph = (const unsigned short*)(wp + (size_t)2 * 9 * C * C);
-        if (launch_conv_stage_once(R, C, ph, x, x_roi_stride, e, as_stream(stream), &rc_so)) return rc_so;
+        const unsigned short* fh = ph + (size_t)4 * 9 * C * C;
+        if (launch_conv_stage_once(R, C, ph, fh, x, x_roi_stride, e, as_stream(stream), &rc_so)) return rc_so;
     }
     return launch_gemm_auto(C, R * 49, C, 9, 1, 1, la, lb, e, as_stream(stream), /*exact=*/false, /*kb_inner=*/true);
 }
@@ -686,7 +693,8 @@ extern "C" int32_t arfe_conv3x3_bwd_data(int32_t R, int32_t C, const void* packe
     {
         int32_t rc_so;
         const unsigned short* pd = (const unsigned short*)((const float*)packed + (size_t)2 * 9 * C * C) + (size_t)2 * 9 * C * C;
-        if (launch_conv_stage_once(R, C, pd, dy, dy_roi_stride, e, as_stream(stream), &rc_so)) return rc_so;
+        const unsigned short* fd = pd + (size_t)2 * 9 * C * C + (size_t)9 * C * C;
+        if (launch_conv_stage_once(R, C, pd, fd, dy, dy_roi_stride, e, as_stream(stream), &rc_so)) return rc_so;
     }
     return launch_gemm_auto(C, R * 49, C, 9, 1, 1, la, lb, e, as_stream(stream), /*exact=*/false, /*kb_inner=*/true);
 }

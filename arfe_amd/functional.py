@@ -5,6 +5,7 @@ Raw ops (`*_op`) allocate outputs/workspaces with torch and call libarfe_hip; th
 Nothing here computes on the CPU or through PyTorch kernels.
 """
 import ctypes
+import os
 
 import torch
 
@@ -64,6 +65,25 @@ def tap_decisions(target):
     """target: a dict to fill during the next forward passes, or None to switch the tap off."""
     global _decision_tap
     _decision_tap = target
+
+
+class lib_precision:
+    """`with lib_precision(half_ops):` - the library's dense contractions take half operands (one f16 MFMA per product, the
+    reference's fp16 mode) for the calls made inside, on THIS thread (arfe_set_operand_precision is per thread: autograd runs
+    the backward on its own thread, so every Function sets the mode it recorded in the forward again in its backward)."""
+
+    def __init__(self, half_ops):
+        self.half_ops = bool(half_ops)
+
+    def __enter__(self):
+        if self.half_ops:
+            check(hip.lib().arfe_set_operand_precision(1), "arfe_set_operand_precision")
+        return self
+
+    def __exit__(self, *exc):
+        if self.half_ops:
+            hip.lib().arfe_set_operand_precision(0)
+        return False
 
 
 def _empty_like_levels(xs):
@@ -270,7 +290,13 @@ class ARFPNFunction(torch.autograd.Function):
     args: refine_level, n, x_0..x_{n-1}, w1_0.., b1_0.., w2_0.., b2_0.., wt, bt, wp, bp, wg, bg, wo, bo"""
 
     @staticmethod
-    def forward(ctx, refine_level, n, *t):
+    def forward(ctx, refine_level, n, half_ops, *t):
+        ctx.half_ops = half_ops
+        with lib_precision(half_ops):
+            return ARFPNFunction._forward(ctx, refine_level, n, *t)
+
+    @staticmethod
+    def _forward(ctx, refine_level, n, *t):
         xs = [v.contiguous() for v in t[0:n]]
         w1, b1 = list(t[n:2 * n]), list(t[2 * n:3 * n])
         w2, b2 = list(t[3 * n:4 * n]), list(t[4 * n:5 * n])
@@ -294,6 +320,11 @@ class ARFPNFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *gouts):
+        with lib_precision(ctx.half_ops):
+            return ARFPNFunction._backward(ctx, *gouts)
+
+    @staticmethod
+    def _backward(ctx, *gouts):
         n, r = ctx.n, ctx.refine_level
         s = ctx.saved_tensors
         xs, w1, w2 = list(s[0:n]), list(s[n:2 * n]), list(s[2 * n:3 * n])
@@ -311,12 +342,12 @@ class ARFPNFunction(torch.autograd.Function):
         dxs = fpn_input_bwd_op(gouts, dpa, dpb, w1, w2, dm, argmax, r)
         join_side(dev)
         del keep
-        return (None, None, *dxs, *dw1, *db1, *dw2, *db2, dwt, dbt, dwp, dbp, dwg, dbg, dwo, dbo)
+        return (None, None, None, *dxs, *dw1, *db1, *dw2, *db2, dwt, dbt, dwp, dbp, dwg, dbg, dwo, dbo)
 
 
-def arfpn(xs, w1, b1, w2, b2, wt, bt, wp, bp, wg, bg, wo, bo, refine_level=2):
+def arfpn(xs, w1, b1, w2, b2, wt, bt, wp, bp, wg, bg, wo, bo, refine_level=2, half_ops=False):
     n = len(xs)
-    return ARFPNFunction.apply(refine_level, n, *xs, *w1, *b1, *w2, *b2, wt, bt, wp, bp, wg, bg, wo, bo)
+    return ARFPNFunction.apply(refine_level, n, bool(half_ops), *xs, *w1, *b1, *w2, *b2, wt, bt, wp, bp, wg, bg, wo, bo)
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -705,7 +736,14 @@ class RFFHeadFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w_wh, b_wh, w_hh, b_hh, w_f, b_f, w1, b1, w2, b2, wc, bc, wr, br, pk_wh=None, pk_hh=None,
-                pk_f=None):
+                pk_f=None, half_ops=False):
+        ctx.half_ops = bool(half_ops)
+        with lib_precision(ctx.half_ops):
+            return RFFHeadFunction._forward(ctx, x, w_wh, b_wh, w_hh, b_hh, w_f, b_f, w1, b1, w2, b2, wc, bc, wr, br, pk_wh,
+                                            pk_hh, pk_f)
+
+    @staticmethod
+    def _forward(ctx, x, w_wh, b_wh, w_hh, b_hh, w_f, b_f, w1, b1, w2, b2, wc, bc, wr, br, pk_wh, pk_hh, pk_f):
         x = x.contiguous()
         ctx.sink1 = grad_sink_of(w1) if w1.is_contiguous() else None
         params = [p.contiguous() for p in (w_wh, b_wh, w_hh, b_hh, w_f, b_f, w1, b1, w2, b2, wc, bc, wr, br)]
@@ -720,13 +758,14 @@ class RFFHeadFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dcls, dreg):
-        dx, pg, _keep = _rff_head_backward(ctx.saved_tensors, dcls, dreg, join=True, sink1=ctx.sink1)
-        return (dx, *pg, None, None, None)
+        with lib_precision(ctx.half_ops):
+            dx, pg, _keep = _rff_head_backward(ctx.saved_tensors, dcls, dreg, join=True, sink1=ctx.sink1)
+        return (dx, *pg, None, None, None, None)
 
 
-def rff_head(x, w_wh, b_wh, w_hh, b_hh, w_f, b_f, w1, b1, w2, b2, wc, bc, wr, br, packed=None):
+def rff_head(x, w_wh, b_wh, w_hh, b_hh, w_f, b_f, w1, b1, w2, b2, wc, bc, wr, br, packed=None, half_ops=False):
     pk = tuple(packed) if packed is not None else (None, None, None)
-    return RFFHeadFunction.apply(x, w_wh, b_wh, w_hh, b_hh, w_f, b_f, w1, b1, w2, b2, wc, bc, wr, br, *pk)
+    return RFFHeadFunction.apply(x, w_wh, b_wh, w_hh, b_hh, w_f, b_f, w1, b1, w2, b2, wc, bc, wr, br, *pk, bool(half_ops))
 
 
 class RFFExtractHeadFunction(torch.autograd.Function):
@@ -816,13 +855,15 @@ class Conv1x1Function(torch.autograd.Function):
     """ConvModule(cin, cout, 1, act_cfg=None): y = W x + b on [B, Cin, H, W] (fpn.py:117-124)."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, half_ops=False):
         x, w, b = x.contiguous(), w.contiguous(), b.contiguous()
         hip.require_f32_cuda(x, w, b)
         B, cin, H, W = x.shape
         cout = w.shape[0]
         y = torch.empty(B, cout, H, W, device=x.device)
-        check(hip.lib().arfe_conv1x1_fwd(B, cin, cout, H * W, ptr(x), ptr(w), ptr(b), ptr(y), stream()), "arfe_conv1x1_fwd")
+        ctx.half_ops = bool(half_ops)
+        with lib_precision(ctx.half_ops):
+            check(hip.lib().arfe_conv1x1_fwd(B, cin, cout, H * W, ptr(x), ptr(w), ptr(b), ptr(y), stream()), "arfe_conv1x1_fwd")
         ctx.save_for_backward(x, w)
         return y
 
@@ -833,21 +874,22 @@ class Conv1x1Function(torch.autograd.Function):
         B, cin, H, W = x.shape
         cout = w.shape[0]
         dx = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
-            check(hip.lib().arfe_conv1x1_bwd_data(B, cin, cout, H * W, ptr(w), ptr(dy), ptr(dx), stream()),
-                  "arfe_conv1x1_bwd_data")
-        dw, db = torch.empty_like(w), torch.empty(cout, device=x.device)
-        check(hip.lib().arfe_conv1x1_bwd_weight(B, cin, cout, H * W, ptr(x), ptr(dy), ptr(dw), ptr(db), stream()),
-              "arfe_conv1x1_bwd_weight")
-        return dx, dw, db
+        with lib_precision(ctx.half_ops):
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x)
+                check(hip.lib().arfe_conv1x1_bwd_data(B, cin, cout, H * W, ptr(w), ptr(dy), ptr(dx), stream()),
+                      "arfe_conv1x1_bwd_data")
+            dw, db = torch.empty_like(w), torch.empty(cout, device=x.device)
+            check(hip.lib().arfe_conv1x1_bwd_weight(B, cin, cout, H * W, ptr(x), ptr(dy), ptr(dw), ptr(db), stream()),
+                  "arfe_conv1x1_bwd_weight")
+        return dx, dw, db, None
 
 
 class ConvMap3x3Function(torch.autograd.Function):
     """ConvModule(c, c, 3, padding=1, act_cfg=None) on whole feature maps (fpn.py:125-133)."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, half_ops=False):
         x, w, b = x.contiguous(), w.contiguous(), b.contiguous()
         hip.require_f32_cuda(x, w, b)
         B, C, H, W = x.shape
@@ -855,7 +897,9 @@ class ConvMap3x3Function(torch.autograd.Function):
             raise hip.ArfeHipError(f"conv3x3 on maps needs square C -> C weights, got {tuple(w.shape)} for C={C}")
         pk = conv3x3_pack_op(w)
         y = torch.empty_like(x)
-        check(hip.lib().arfe_convmap3x3_fwd(B, C, H, W, ptr(x), ptr(pk), ptr(b), ptr(y), stream()), "arfe_convmap3x3_fwd")
+        ctx.half_ops = bool(half_ops)
+        with lib_precision(ctx.half_ops):
+            check(hip.lib().arfe_convmap3x3_fwd(B, C, H, W, ptr(x), ptr(pk), ptr(b), ptr(y), stream()), "arfe_convmap3x3_fwd")
         ctx.save_for_backward(x, w, pk)
         return y
 
@@ -865,15 +909,16 @@ class ConvMap3x3Function(torch.autograd.Function):
         dy = dy.contiguous()
         B, C, H, W = x.shape
         dx = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
-            check(hip.lib().arfe_convmap3x3_bwd_data(B, C, H, W, ptr(pk), ptr(dy), ptr(dx), stream()),
-                  "arfe_convmap3x3_bwd_data")
-        dw, db = torch.empty_like(w), torch.empty(C, device=x.device)
-        ws = _ws(hip.lib().arfe_conv3x3_workspace_bytes(C), x.device)
-        check(hip.lib().arfe_convmap3x3_bwd_weight(B, C, H, W, ptr(x), ptr(dy), ptr(dw), ptr(db), ptr(ws), stream()),
-              "arfe_convmap3x3_bwd_weight")
-        return dx, dw, db
+        with lib_precision(ctx.half_ops):
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x)
+                check(hip.lib().arfe_convmap3x3_bwd_data(B, C, H, W, ptr(pk), ptr(dy), ptr(dx), stream()),
+                      "arfe_convmap3x3_bwd_data")
+            dw, db = torch.empty_like(w), torch.empty(C, device=x.device)
+            ws = _ws(hip.lib().arfe_conv3x3_workspace_bytes(C), x.device)
+            check(hip.lib().arfe_convmap3x3_bwd_weight(B, C, H, W, ptr(x), ptr(dy), ptr(dw), ptr(db), ptr(ws), stream()),
+                  "arfe_convmap3x3_bwd_weight")
+        return dx, dw, db, None
 
 
 class NearestAddFunction(torch.autograd.Function):
@@ -921,12 +966,12 @@ class Subsample2Function(torch.autograd.Function):
         return dx
 
 
-def conv1x1(x, w, b):
-    return Conv1x1Function.apply(x, w, b)
+def conv1x1(x, w, b, half_ops=False):
+    return Conv1x1Function.apply(x, w, b, bool(half_ops))
 
 
-def convmap3x3(x, w, b):
-    return ConvMap3x3Function.apply(x, w, b)
+def convmap3x3(x, w, b, half_ops=False):
+    return ConvMap3x3Function.apply(x, w, b, bool(half_ops))
 
 
 def nearest_add(lat, top):
@@ -995,9 +1040,14 @@ def f32_boundary(tensors, params, what):
     `finish(out)` returning the outputs in the module's storage dtype (half in fp16 mode)."""
     dt = storage_dtype(tensors, params, what)
     if dt == torch.float32:
-        return list(tensors), list(params), lambda out: out
+        def same(out):
+            return out
+        same.half_ops = False
+        return list(tensors), list(params), same
     def finish(out):
         if isinstance(out, (tuple, list)):
             return type(out)(to_f16(o) for o in out)
         return to_f16(out)
+    # half storage = the reference's fp16 mode: the module's contractions take half operands (pass finish.half_ops on)
+    finish.half_ops = os.environ.get('ARFE_FP16_F32_PRODUCTS', '0') != '1'
     return [to_f32(t) for t in tensors], [to_f32(p) for p in params], finish

@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ARFE_LIB", os.path.join(_HERE, "libarfe_hip.so"))   # ARFE_LIB: development builds only
 MAX_LEVELS = 8
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 c_f32p = ctypes.c_void_p
 _i32, _i64, _vp, _f32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_float
@@ -39,6 +39,8 @@ _PP = ctypes.POINTER(Pyramid)
 SIGNATURES = {
     "arfe_last_error": (ctypes.c_char_p, []),
     "arfe_abi_version": (_i32, []),
+    "arfe_set_operand_precision": (_i32, [_i32]),
+    "arfe_get_operand_precision": (_i32, []),
     "arfe_fpn_gather_fwd": (_i32, [_PP, _vp, _vp, _vp, _vp]),
     "arfe_fpn_gatemap_workspace_bytes": (_i64, [_PP]),
     "arfe_fpn_gatemap_fwd": (_i32, [_PP, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -43,7 +43,7 @@ class WFPNDualSpatial(nn.Module):
         n = self.num_levels
         xs, p, finish = Fn.f32_boundary(inputs, w1 + b1 + w2 + b2 + list(self.refine.hip_params()), 'WFPNDualSpatial')
         return finish(tuple(Fn.arfpn(xs, p[:n], p[n:2 * n], p[2 * n:3 * n], p[3 * n:4 * n], *p[4 * n:],
-                                     refine_level=self.refine_level)))
+                                     refine_level=self.refine_level, half_ops=finish.half_ops)))
 
 
 @NECKS.register_module()
@@ -98,10 +98,11 @@ class FPN(nn.Module):
         used = len(self.lateral_convs)
         params = [t for m in list(self.lateral_convs) + list(self.fpn_convs) for t in (m.conv.weight, m.conv.bias)]
         xs, p, finish = Fn.f32_boundary(inputs, params, 'FPN')
-        laterals = [Fn.conv1x1(xs[i + self.start_level], p[2 * i], p[2 * i + 1]) for i in range(used)]
+        h16 = finish.half_ops
+        laterals = [Fn.conv1x1(xs[i + self.start_level], p[2 * i], p[2 * i + 1], h16) for i in range(used)]
         for i in range(used - 1, 0, -1):
             laterals[i - 1] = Fn.nearest_add(laterals[i - 1], laterals[i])
-        outs = [Fn.convmap3x3(laterals[i], p[2 * (used + i)], p[2 * (used + i) + 1]) for i in range(used)]
+        outs = [Fn.convmap3x3(laterals[i], p[2 * (used + i)], p[2 * (used + i) + 1], h16) for i in range(used)]
         for _ in range(self.num_outs - used):
             outs.append(Fn.subsample2(outs[-1]))
         return finish(tuple(outs))

@@ -9,17 +9,20 @@ from .cnn import ConvModule, constant_init, normal_init
 
 class _NonLocalFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, m, wt, bt, wp, bp, wg, bg, wo, bo):
+    def forward(ctx, m, wt, bt, wp, bp, wg, bg, wo, bo, half_ops=False):
         m = m.contiguous()
-        bsf, saved = Fn.nonlocal_fwd_op(m, wt, bt, wp, bp, wg, bg, wo, bo)
+        ctx.half_ops = bool(half_ops)
+        with Fn.lib_precision(ctx.half_ops):
+            bsf, saved = Fn.nonlocal_fwd_op(m, wt, bt, wp, bp, wg, bg, wo, bo)
         ctx.save_for_backward(m, wt, wp, wg, wo, *saved)
         return bsf
 
     @staticmethod
     def backward(ctx, dbsf):
         m, wt, wp, wg, wo, tpg, P, y = ctx.saved_tensors
-        dm, (dwt, dbt, dwp, dbp, dwg, dbg, dwo, dbo) = Fn.nonlocal_bwd_op(dbsf.contiguous(), m, wt, wp, wg, wo, (tpg, P, y))
-        return dm, dwt, dbt, dwp, dbp, dwg, dbg, dwo, dbo
+        with Fn.lib_precision(ctx.half_ops):
+            dm, (dwt, dbt, dwp, dbp, dwg, dbg, dwo, dbo) = Fn.nonlocal_bwd_op(dbsf.contiguous(), m, wt, wp, wg, wo, (tpg, P, y))
+        return dm, dwt, dbt, dwp, dbp, dwg, dbg, dwo, dbo, None
 
 
 class NonLocal2D(nn.Module):
@@ -59,4 +62,4 @@ class NonLocal2D(nn.Module):
 
     def forward(self, x):
         (x,), p, finish = Fn.f32_boundary([x], self.hip_params(), 'NonLocal2D')
-        return finish(_NonLocalFunction.apply(x, *p))
+        return finish(_NonLocalFunction.apply(x, *p, finish.half_ops))

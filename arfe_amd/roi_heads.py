@@ -277,7 +277,7 @@ class MultiBBoxHead(BBoxHead):
         # from the extractor (out_fp16) and meets half parameters
         params = self._params()
         (x,), p, finish = Fn.f32_boundary([x], params, 'MultiBBoxHead')
-        return finish(Fn.rff_head(x, *p, packed=packed if x.dtype == torch.float32 else None))
+        return finish(Fn.rff_head(x, *p, packed=packed if x.dtype == torch.float32 else None, half_ops=finish.half_ops))
 
 
 @HEADS.register_module()

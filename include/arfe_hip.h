@@ -24,7 +24,8 @@
 extern "C" {
 #endif
 
-#define ARFE_ABI_VERSION 2   /* 2: arfe_linear_fwd / _bwd take an optional split-K scratch (workspace, workspace_bytes) */
+#define ARFE_ABI_VERSION 3   /* 2: arfe_linear_fwd / _bwd take an optional split-K scratch (workspace, workspace_bytes)
+                              * 3: arfe_set_operand_precision, arfe_fpn_gather_gate_fwd; the conv3x3 pack holds half planes too */
 #define ARFE_MAX_LEVELS 8
 
 #define ARFE_OK 0
@@ -43,6 +44,17 @@ typedef struct arfe_pyramid {
 
 const char* arfe_last_error(void);
 int32_t arfe_abi_version(void);
+
+/* Operand precision of the dense contractions (3x3 / 1x1 convs, linear layers, the NonLocal products), PER CALLING THREAD:
+ *   0 (default)  fp32 operands: every product is the three-term bf16 split on the matrix pipe (six terms for the softmax
+ *                logits), ~1e-5 relative - the fp32 reference's arithmetic to parity tolerance;
+ *   1            half operands: each operand is rounded to IEEE half on its way into LDS and every product is ONE f16 MFMA with
+ *                fp32 accumulation - the arithmetic of the reference's fp16 mode (mmdet/core/fp16/hooks.py:86-105:
+ *                model.half()), exact for tensors that are stored as half.
+ * The mode is thread-local (no state shared between threads); host code sets it around the calls of a module that runs in
+ * fp16 mode, in the forward and again in the backward (autograd's thread).  ARFE_GEMM_F32=1 overrides both. */
+int32_t arfe_set_operand_precision(int32_t mode);
+int32_t arfe_get_operand_precision(void);
 
 /* ======================================================================================================
  * AR-FPN  (mmdet/models/necks/wfpn_dual_spatial.py: WFPNDualSpatial.forward :99-137)

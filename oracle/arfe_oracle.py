@@ -417,7 +417,7 @@ def half_store(t):
     return _HalfStore.apply(t)
 
 
-def fp16_mode_forward(xs, p_fpn, p_neck, p_head, rois, num_outs=5, refine_level=2):
+def fp16_mode_forward(xs, p_fpn, p_neck, p_head, rois, num_outs=5, refine_level=2, decisions=None):
     """The path after wrap_fp16_model (mmdet/core/fp16/hooks.py:86-105): parameters hold half values (pass them as
     the fp32 images of those halves), FPN.forward casts its inputs to half (@auto_fp16, fpn.py:166), the neck and the
     head run on half tensors, the RoI extractor computes in fp32 and returns half (@force_fp32(feats), out_fp16,
@@ -426,9 +426,9 @@ def fp16_mode_forward(xs, p_fpn, p_neck, p_head, rois, num_outs=5, refine_level=
     its half kernels; tests bound that difference against fixtures made by the reference itself).
     -> (pyramid, feats, bbox_feats, cls, reg), fp32 tensors holding half-representable values."""
     pyr = [half_store(t) for t in fpn_forward([half_store(x) for x in xs], p_fpn, num_outs)]
-    feats = [half_store(t) for t in arfpn_forward(pyr, p_neck, refine_level)]
+    feats = [half_store(t) for t in arfpn_forward(pyr, p_neck, refine_level, decisions=decisions)]
     bbox_feats = half_store(roi_extract3(feats, rois))
-    cls, reg = rff_head(bbox_feats, p_head)
+    cls, reg = rff_head(bbox_feats, p_head, decisions=decisions)
     return pyr, feats, bbox_feats, half_store(cls), half_store(reg)
 
 

@@ -913,6 +913,47 @@ assert e <= 2e-6, e
     assert out.returncode == 0, out.stdout + out.stderr
 
 
+@pytest.mark.parametrize('R', [1024, 96])
+def test_half_operand_mode_is_exact_for_half_values(Fn, dev, R):
+    """arfe_set_operand_precision(1) - the contraction arithmetic of the reference's fp16 mode: operands go to the matrix pipe as
+    IEEE halves, ONE f16 MFMA per product, fp32 accumulation.  For tensors whose values are half-representable every product
+    is exact, so 3x3 conv (stage-once kernel at R = 1024, generic GEMM kernel at R = 96), its two gradients and a linear layer must
+    match an fp64 evaluation to fp32 accumulation error; the mode is per thread and off again after the block."""
+    import torch.nn.functional as F
+    from arfe_amd import hip
+    g = torch.Generator().manual_seed(31)
+    C = 128
+    h = lambda t: t.half().float()
+    x = h(torch.randn(R, C, 7, 7, generator=g))
+    w = h(torch.randn(C, C, 3, 3, generator=g) * 0.05)
+    b = h(torch.randn(C, generator=g) * 0.1)
+    dy = h(torch.randn(R, C, 7, 7, generator=g))
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    y_ref = F.conv2d(xr, wr, b.double(), padding=1)
+    y_ref.backward(dy.double())
+    xd, wd, bd, dyd = x.to(dev), w.to(dev), b.to(dev), dy.to(dev)
+    assert hip.lib().arfe_get_operand_precision() == 0
+    with Fn.lib_precision(True):
+        assert hip.lib().arfe_get_operand_precision() == 1
+        pk = Fn.conv3x3_pack_op(wd)
+        y = Fn.conv3x3_fwd_op(xd.data_ptr(), C * 49, R, C, pk, bd, False)
+        dx = torch.empty_like(xd)
+        Fn.conv3x3_bwd_data_op(R, C, pk, dyd, dx.data_ptr(), C * 49)
+        ws = torch.empty(int(hip.lib().arfe_conv3x3_workspace_bytes(C)), dtype=torch.uint8, device=dev)
+        dw, db = Fn.conv3x3_bwd_weight_op(xd.data_ptr(), C * 49, R, C, wd, dyd, ws)
+        lw = h(torch.randn(200, C * 49, generator=g) * 0.02)
+        lb = h(torch.randn(200, generator=g))
+        ly = Fn.linear_fwd_op(xd.view(R, C * 49), lw.to(dev), lb.to(dev), False)
+    assert hip.lib().arfe_get_operand_precision() == 0
+    assert relerr(y, y_ref.detach().float()) <= 2e-6
+    assert relerr(dx, xr.grad.float()) <= 2e-6
+    assert relerr(dw, wr.grad.float()) <= 5e-6
+    assert relerr(ly, F.linear(x.double().view(R, -1), lw.double(), lb.double()).float()) <= 2e-6
+    # the default mode on the same inputs agrees to its own (bf16x3) accuracy
+    y3 = Fn.conv3x3_fwd_op(xd.data_ptr(), C * 49, R, C, pk, bd, False)
+    assert relerr(y3, y_ref.detach().float()) <= TOL
+
+
 def test_cast_kernels_match_tensor_to(Fn, dev):
     """arfe_cast_*: round to nearest even, inf/nan/subnormals, unaligned views and ragged tails like Tensor.to."""
     g = torch.Generator().manual_seed(5)
@@ -931,12 +972,18 @@ def test_cast_kernels_match_tensor_to(Fn, dev):
     assert Fn.to_f16(torch.empty(0, device=dev)).numel() == 0
 
 
-def test_fp16_mode_through_plugin_surface(O, dev):
+@pytest.mark.parametrize('products', ['half', 'f32'])
+def test_fp16_mode_through_plugin_surface(O, dev, products, monkeypatch):
     """wrap_fp16_model on registry-built FPN -> WFPNDualSpatial -> StandardRoIHead: half parameters and activations at
     the module boundaries (dtypes as in the reference), compared (a) tightly with the oracle's restatement of the same
     storage contract and (b) with the fixture the reference produced in its own fp16 mode, within the bounds of
-    conftest (the reference's half kernels are the noisier side)."""
+    conftest (the reference's half kernels are the noisier side).
+    products: 'half' (default) - the contractions take half operands, one f16 MFMA per product as in the reference's half
+    kernels (intermediates that feed a contraction are rounded to half, so gradients sit ~1 % from the fp32 evaluation - still
+    2-5x closer than the reference's own half run); 'f32' (ARFE_FP16_F32_PRODUCTS=1) - fp32-grade products, round 2's form."""
     import arfe_amd
+    monkeypatch.setenv('ARFE_FP16_F32_PRODUCTS', '1' if products == 'f32' else '0')
+    GRAD_A = 5e-3 if products == 'f32' else 2.5e-2
     from conftest import FP16_FWD_TOL, check_fp16_grads, fp16_fixture
     d, xs_cpu, P = fp16_fixture()
     C = 8
@@ -957,9 +1004,17 @@ def test_fp16_mode_through_plugin_surface(O, dev):
     assert all(p.dtype == torch.float16 for m in mods for p in m.parameters())
     assert fpn.fp16_enabled and roi_head.bbox_roi_extractor.fp16_enabled and roi_head.bbox_head.fp16_enabled
     xs = [x.detach().to(dev).requires_grad_(True) for x in xs_cpu]
-    pyr = fpn(xs)                                        # fp32 in, half out (@auto_fp16)
-    feats = neck(pyr)
-    res = roi_head._bbox_forward(feats, d['rois'].to(dev))
+    from arfe_amd import functional as FnT
+    from oracle import parity as PT
+    tap = {}
+    FnT.tap_decisions(tap)
+    try:
+        pyr = fpn(xs)                                        # fp32 in, half out (@auto_fp16)
+        feats = neck(pyr)
+        res = roi_head._bbox_forward(feats, d['rois'].to(dev))
+    finally:
+        FnT.tap_decisions(None)
+    dz = PT.decisions_from_tap(tap, 2)
     cls, reg, bbox_feats = res['cls_score'], res['bbox_pred'], res['bbox_feats']
     assert all(t.dtype == torch.float16 for t in (*pyr, *feats, bbox_feats, cls, reg))
     ((cls * d['cot_cls'].to(dev)).sum() + (reg * d['cot_reg'].to(dev)).sum()).backward()
@@ -969,8 +1024,11 @@ def test_fp16_mode_through_plugin_surface(O, dev):
     assert all(g is None or g.dtype == torch.float16 for gs in grads.values() for g in gs.values())
     assert all(x.grad.dtype == torch.float32 for x in xs)
 
-    # (a) same storage contract, fp32 oracle: differences are single half-ulp rounding flips (2^-11 relative)
-    o_pyr, o_feats, o_bbox, o_cls, o_reg = O.fp16_mode_forward(xs_cpu, P['fpn.'], P['neck.'], P['head.'], d['rois'])
+    # (a) same storage contract, fp32 oracle evaluated under the device's ReLU / argmax choices (a ReLU that opens on one
+    # side only moves every gradient of this small fixture by percents: oracle/arfe_oracle.Decisions): differences are
+    # single half-ulp rounding flips (2^-11 relative)
+    o_pyr, o_feats, o_bbox, o_cls, o_reg = O.fp16_mode_forward(xs_cpu, P['fpn.'], P['neck.'], P['head.'], d['rois'],
+                                                               decisions=dz)
     HALF_ULP = 2e-3
     for i in range(5):
         assert relerr(pyr[i], o_pyr[i]) <= HALF_ULP and relerr(feats[i], o_feats[i]) <= HALF_ULP, i
@@ -978,14 +1036,19 @@ def test_fp16_mode_through_plugin_surface(O, dev):
     assert relerr(cls, o_cls) <= HALF_ULP and relerr(reg, o_reg) <= HALF_ULP
     ((o_cls * d['cot_cls'].float()).sum() + (o_reg * d['cot_reg'].float()).sum()).backward()
     for i in range(4):
-        assert relerr_l2(xs[i].grad, xs_cpu[i].grad) <= 5e-3, i
+        assert relerr_l2(xs[i].grad, xs_cpu[i].grad) <= GRAD_A, i
     for tag, gs in grads.items():
         for k, g in gs.items():
             og = P[tag][k].grad
             if og is None or k == 'refine.phi.conv.bias':
                 continue
-            # the product rounds each parameter gradient to half once (storage); the oracle's stays fp32
-            assert relerr_l2(g, og) <= 5e-3, tag + k
+            # the product rounds each parameter gradient to half once (storage); the oracle's stays fp32.
+            # NonLocal bias gradients with half operands: the softmax backward dS = P (dP - delta) keeps a row-sum residue once
+            # P and dP are rounded on their way into the MFMA, and these plain sums over L^2 entries collect it.  The
+            # reference's own half kernels show the same (conftest.FP16_GRAD_TOL).
+            from conftest import FP16_GRAD_TOL
+            tol = FP16_GRAD_TOL if (products == 'half' and k.startswith('refine.') and k.endswith('bias')) else GRAD_A
+            assert relerr_l2(g, og) <= tol, (tag + k, relerr_l2(g, og))
 
     # (b) the reference's own half run
     for i in range(5):
@@ -1030,23 +1093,41 @@ def test_cascade_roi_head_in_fp16_mode_matches_oracle(O, dev):
         arfe_amd.wrap_fp16_model(m)
     assert all(p.dtype == torch.float16 for m in mods for p in m.parameters())
     xs = [x.detach().to(dev).requires_grad_(True) for x in xs_cpu]
-    feats = neck(fpn(xs))
+    from arfe_amd import functional as FnT
+    from oracle import parity as PT
+    tap = {}
+    FnT.tap_decisions(tap)
+    try:
+        feats = neck(fpn(xs))
+    finally:
+        FnT.tap_decisions(None)
+    neck_tap = dict(tap)
     rois = d['rois']
     # oracle: shared trunk once, one head per stage
     xo = [x.detach().clone().requires_grad_(True) for x in xs_cpu]
     Pf = {k: v.detach().clone().requires_grad_(True) for k, v in P['fpn.'].items()}
     Pn = {k: v.detach().clone().requires_grad_(True) for k, v in P['neck.'].items()}
     o_pyr = [O.half_store(t) for t in O.fpn_forward([O.half_store(x) for x in xo], Pf, 5)]
-    o_feats = [O.half_store(t) for t in O.arfpn_forward(o_pyr, Pn, 2)]
+    # the oracle runs under the device's ReLU / argmax choices (oracle/arfe_oracle.Decisions): a mask that flips under half
+    # arithmetic moves the gradients of this small fixture by percents and is not an arithmetic error
+    dz_neck = O.Decisions(argmax=[neck_tap['argmax'][i].cpu().long() for i in range(2)],
+                          gate_a=[t.cpu() > 0 for t in neck_tap['gate_a']], gate_b=[t.cpu() > 0 for t in neck_tap['gate_b']])
+    o_feats = [O.half_store(t) for t in O.arfpn_forward(o_pyr, Pn, 2, decisions=dz_neck)]
     HALF_ULP = 2e-3
     loss, o_loss = 0., 0.
     for st in range(3):
         r = rois.clone()
         r[:, 1:] += 2.0 * st
-        res = rh._bbox_forward(st, feats, r.to(dev))
+        tap = {}
+        FnT.tap_decisions(tap)
+        try:
+            res = rh._bbox_forward(st, feats, r.to(dev))
+        finally:
+            FnT.tap_decisions(None)
+        dz_head = O.Decisions(**{k: tap[k].cpu() > 0 for k in ('lw', 'lh', 'z2', 'f1', 'f2')})
         assert res['cls_score'].dtype == torch.float16 and res['bbox_pred'].dtype == torch.float16
         o_bbox = O.half_store(O.roi_extract3(o_feats, r))
-        o_cls, o_reg = O.rff_head(o_bbox, stage_params[st])
+        o_cls, o_reg = O.rff_head(o_bbox, stage_params[st], decisions=dz_head)
         o_cls, o_reg = O.half_store(o_cls), O.half_store(o_reg)
         assert relerr(res['bbox_feats'], o_bbox) <= HALF_ULP, st
         assert relerr(res['cls_score'], o_cls) <= HALF_ULP and relerr(res['bbox_pred'], o_reg) <= HALF_ULP, st
@@ -1056,19 +1137,23 @@ def test_cascade_roi_head_in_fp16_mode_matches_oracle(O, dev):
         o_loss = o_loss + (o_cls * c1).sum() + (o_reg * c2).sum()
     loss.backward()
     o_loss.backward()
+    GR = 2.5e-2          # half-operand contractions (see test_fp16_mode_through_plugin_surface)
     for i in range(4):
-        assert relerr_l2(xs[i].grad, xo[i].grad) <= 8e-3, i
+        assert relerr_l2(xs[i].grad, xo[i].grad) <= GR, i
     for st in range(3):
+        from conftest import FP16_GRAD_TOL
         for k, v in rh.bbox_head[st].named_parameters():
             assert v.grad.dtype == torch.float16
-            assert relerr_l2(v.grad, stage_params[st][k].grad) <= 8e-3, (st, k)
+            assert relerr_l2(v.grad, stage_params[st][k].grad) <= GR, (st, k, relerr_l2(v.grad, stage_params[st][k].grad))
     for k, v in neck.named_parameters():
         if k == 'refine.phi.conv.bias':
             continue
         if Pn[k].grad is None:          # the gate conv of a level no RoI maps to: no gradient in the reference, none / zero here
             assert v.grad is None or float(v.grad.float().abs().max()) == 0.0, k
             continue
-        assert relerr_l2(v.grad, Pn[k].grad) <= 8e-3, k
+        from conftest import FP16_GRAD_TOL
+        tol = FP16_GRAD_TOL if (k.startswith('refine.') and k.endswith('bias')) else GR   # see test_fp16_mode_through_plugin_surface
+        assert relerr_l2(v.grad, Pn[k].grad) <= tol, (k, relerr_l2(v.grad, Pn[k].grad))
 
 
 def test_fp16_mode_dtype_mismatch_raises_like_the_reference(dev):
