@@ -106,7 +106,63 @@ __global__ __launch_bounds__(256) void cast_f2h_kernel(const float* __restrict__
     }
 }
 
+// many small tensors in ONE launch (the parameters of a module that runs in fp16 mode: 14 - 28 tensors per boundary and
+// direction, each a 2 - 7 us launch on its own): blockIdx.y = tensor, grid-stride over its elements
+constexpr int CAST_MULTI_MAX = 48;
+struct CastList { const void* src[CAST_MULTI_MAX]; void* dst[CAST_MULTI_MAX]; int64_t n[CAST_MULTI_MAX]; };
+template <bool TO_HALF>
+__global__ __launch_bounds__(256) void cast_multi_kernel(CastList l) {
+    const int t = blockIdx.y;
+    const int64_t n = l.n[t];
+    const int64_t stride = (int64_t)gridDim.x * 256 * 8;
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8; i < n; i += stride) {
+        if constexpr (TO_HALF) {
+            const float* s = (const float*)l.src[t];
+            _Float16* d = (_Float16*)l.dst[t];
+            if ((((uintptr_t)s & 31) | ((uintptr_t)d & 15)) == 0 && i + 7 < n) {
+                *reinterpret_cast<half8*>(d + i) = __builtin_convertvector(*reinterpret_cast<const float8*>(s + i), half8);
+            } else {
+                for (int e = 0; e < 8 && i + e < n; ++e) d[i + e] = (_Float16)s[i + e];
+            }
+        } else {
+            const _Float16* s = (const _Float16*)l.src[t];
+            float* d = (float*)l.dst[t];
+            if ((((uintptr_t)s & 15) | ((uintptr_t)d & 31)) == 0 && i + 7 < n) {
+                *reinterpret_cast<float8*>(d + i) = __builtin_convertvector(*reinterpret_cast<const half8*>(s + i), float8);
+            } else {
+                for (int e = 0; e < 8 && i + e < n; ++e) d[i + e] = (float)s[i + e];
+            }
+        }
+    }
+}
+
 }  // namespace arfe
+
+extern "C" int32_t arfe_cast_multi(int32_t count, const void* const* src, void* const* dst, const int64_t* n, int32_t to_half,
+                                   void* stream) {
+    using namespace arfe;
+    ARFE_CHECK_ARG(count >= 0 && (count == 0 || (src && dst && n)), ARFE_ERR_ARG, "cast_multi: bad arguments");
+    for (int base = 0; base < count; base += CAST_MULTI_MAX) {
+        CastList l;
+        int m = 0;
+        int64_t mx = 0;
+        for (int i = base; i < count && m < CAST_MULTI_MAX; ++i) {
+            ARFE_CHECK_ARG(n[i] >= 0, ARFE_ERR_ARG, "cast_multi: tensor %d has %lld elements", i, (long long)n[i]);
+            if (n[i] == 0) continue;
+            ARFE_CHECK_ARG(src[i] && dst[i], ARFE_ERR_ARG, "cast_multi: null pointer (tensor %d)", i);
+            l.src[m] = src[i]; l.dst[m] = dst[i]; l.n[m] = n[i];
+            mx = n[i] > mx ? n[i] : mx;
+            ++m;
+        }
+        if (m == 0) continue;
+        int64_t gx = cdiv64(mx, 256 * 8 * 2);
+        gx = gx < 1 ? 1 : (gx > 2048 ? 2048 : gx);
+        if (to_half) hipLaunchKernelGGL(cast_multi_kernel<true>, dim3((unsigned)gx, m), dim3(256), 0, as_stream(stream), l);
+        else hipLaunchKernelGGL(cast_multi_kernel<false>, dim3((unsigned)gx, m), dim3(256), 0, as_stream(stream), l);
+        ARFE_CHECK_LAUNCH();
+    }
+    return ARFE_OK;
+}
 
 extern "C" int32_t arfe_cast_f16_to_f32(int64_t n, const void* src, float* dst, void* stream) {
     using namespace arfe;

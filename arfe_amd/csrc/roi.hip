@@ -371,10 +371,14 @@ __global__ __launch_bounds__(256) void roi_rank_kernel(int n, const uint32_t* __
 
 constexpr int RF_ROWS = 8;  // window rows in flight per lane
 constexpr int RF_CH = 32;   // channels per block: C/32 = 8 slices of a 256-channel map, one per XCD (see the block map)
+// FT / OT: storage type of the feature maps / of the output (float, or _Float16 in the reference's fp16 mode, where the
+// extractor reads the half maps a neck handed on and hands half RoI features to the head: the values it computes with are the
+// same as after a conversion pass, the arithmetic is fp32 either way - single_level.py:109 @force_fp32(out_fp16=True))
+template <class FT, class OT>
 __global__ __launch_bounds__(256) void roialign_fwd_sep_kernel(RoiLevels L, RoiSets S, int P, int sample_num,
                                                                const RoiWeightHdr* __restrict__ hdr,
                                                                const float* __restrict__ wtab, int nslices,
-                                                               float* __restrict__ out, int64_t out_roi_stride) {
+                                                               OT* __restrict__ out, int64_t out_roi_stride) {
     __shared__ __attribute__((aligned(16))) float wyT_s[RW_EXT][8];   // [window row][bin], pre-scaled by 1/samples
     __shared__ float wx_s[7][RW_EXT];
     __shared__ float U_s[4][7][64];                                    // one 64-column chunk of a wave's row sums
@@ -391,24 +395,24 @@ __global__ __launch_bounds__(256) void roialign_fwd_sep_kernel(RoiLevels L, RoiS
     const int ncc = L.C - c0 < RF_CH ? L.C - c0 : RF_CH;
     const int lvl = hp->lvl;
     int H = L.H[0], W = L.W[0];
-    const float* feat = L.feat[0];
+    const FT* feat = (const FT*)L.feat[0];
 #pragma unroll
     for (int i = 1; i < ARFE_MAX_LEVELS; ++i)
-        if (i == lvl) { H = L.H[i]; W = L.W[i]; feat = L.feat[i]; }
+        if (i == lvl) { H = L.H[i]; W = L.W[i]; feat = (const FT*)L.feat[i]; }
     const int bimg = hp->img;
-    float* obase = out + (int64_t)k * out_roi_stride + ((int64_t)s * L.C + c0) * 49;
+    OT* obase = out + (int64_t)k * out_roi_stride + ((int64_t)s * L.C + c0) * 49;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int big = hp->big;
 
     if (big == 2) {     // every sample falls outside the feature map (or negative size): zeros
-        for (int o = tid; o < ncc * 49; o += 256) obase[o] = 0.f;
+        for (int o = tid; o < ncc * 49; o += 256) obase[o] = (OT)0.f;
         return;
     }
     if (big) {          // sampling form (reference order), one thread per output element
         const RoiGeom g = roi_geom(S.rois[s] + 5 * (int64_t)k, L.scale[lvl], P, sample_num);
         for (int o = tid; o < ncc * 49; o += 256) {
             const int c = o / 49, q = o - c * 49, ph = q / 7, pw = q - ph * 7;
-            const float* f = feat + ((int64_t)bimg * L.C + c0 + c) * H * W;
+            const FT* f = feat + ((int64_t)bimg * L.C + c0 + c) * H * W;
             float acc = 0.f;
             for (int iy = 0; iy < g.grid_h; ++iy) {
                 const float yy = g.y_start + ph * g.bin_h + ((float)iy + 0.5f) * g.bin_h / (float)g.grid_h;
@@ -419,11 +423,11 @@ __global__ __launch_bounds__(256) void roialign_fwd_sep_kernel(RoiLevels L, RoiS
                     int x0, x1; float wx0, wx1;
                     const bool okx = axis_tap(xx, W, x0, x1, wx0, wx1);
                     if (!(oky && okx)) continue;
-                    acc += wy0 * wx0 * f[y0 * W + x0] + wy0 * wx1 * f[y0 * W + x1] + wy1 * wx0 * f[y1 * W + x0] +
-                           wy1 * wx1 * f[y1 * W + x1];
+                    acc += wy0 * wx0 * (float)f[y0 * W + x0] + wy0 * wx1 * (float)f[y0 * W + x1] + wy1 * wx0 * (float)f[y1 * W + x0] +
+                           wy1 * wx1 * (float)f[y1 * W + x1];
                 }
             }
-            obase[o] = acc / g.count;
+            obase[o] = (OT)(acc / g.count);
         }
         return;
     }
@@ -460,12 +464,12 @@ __global__ __launch_bounds__(256) void roialign_fwd_sep_kernel(RoiLevels L, RoiS
             float wide_sum = 0.f;
             for (int ch = 0; ch < nchunk; ++ch) {
                 const int colk = ch * 64 + lane < wext ? ch * 64 + lane : wext - 1;
-                const float* f = feat + (((int64_t)bimg * L.C + c0 + cb) * H + h_s.y0) * W + h_s.x0 + colk;
+                const FT* f = feat + (((int64_t)bimg * L.C + c0 + cb) * H + h_s.y0) * W + h_s.x0 + colk;
                 float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 for (int y = 0; y < hext; y += 4) {
                     float v[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = f[(int64_t)(y + j < hext ? y + j : hext - 1) * W];
+                    for (int j = 0; j < 4; ++j) v[j] = (float)f[(int64_t)(y + j < hext ? y + j : hext - 1) * W];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float4_u wa = *reinterpret_cast<const float4_u*>(&wyT_s[y + j][0]);
@@ -485,18 +489,18 @@ __global__ __launch_bounds__(256) void roialign_fwd_sep_kernel(RoiLevels L, RoiS
                 __builtin_amdgcn_s_waitcnt(0xc07f);     // the row sums are read before the next chunk overwrites them
                 __builtin_amdgcn_wave_barrier();
             }
-            if (lane < 49) obase[cb * 49 + lane] = wide_sum;
+            if (lane < 49) obase[cb * 49 + lane] = (OT)wide_sum;
         }
         return;
     }
     for (int cb = wave * pack; cb < ncc; cb += 4 * pack) {
         const int c = cb + half;
-        const float* f = feat + (((int64_t)bimg * L.C + c0 + (c < ncc ? c : cb)) * H + h_s.y0) * W + h_s.x0 + colc;
+        const FT* f = feat + (((int64_t)bimg * L.C + c0 + (c < ncc ? c : cb)) * H + h_s.y0) * W + h_s.x0 + colc;
         float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         for (int y = 0; y < hext; y += RF_ROWS) {
             float v[RF_ROWS];
 #pragma unroll
-            for (int j = 0; j < RF_ROWS; ++j) v[j] = f[(int64_t)(y + j < hext ? y + j : hext - 1) * W];
+            for (int j = 0; j < RF_ROWS; ++j) v[j] = (float)f[(int64_t)(y + j < hext ? y + j : hext - 1) * W];
             // rows past the window (y + j >= hext) carry zero weight in the table: no branch per row
 #pragma unroll
             for (int j = 0; j < RF_ROWS; ++j) {
@@ -514,7 +518,7 @@ __global__ __launch_bounds__(256) void roialign_fwd_sep_kernel(RoiLevels L, RoiS
             if (lane < 49 && cb + hh < ncc) {
                 float acc2 = 0.f;
                 for (int x = xlo; x < xhi; ++x) acc2 += U_s[wave][qph][hh * pw_cols + x] * wx_s[qpw][x];
-                obase[(cb + hh) * 49 + lane] = acc2;
+                obase[(cb + hh) * 49 + lane] = (OT)acc2;
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -576,8 +580,10 @@ __global__ __launch_bounds__(256) void roi_zero_sliced_tiles_kernel(RoiLevels L,
 }
 
 static_assert(RB_CC % 8 == 0 && RT == 16, "the MFMA tiles are 16x16: a wave owns RB_CC / 4 channels (pairs in the C phase), a tile is 16x16 pixels");
+// GT / DT: storage type of the incoming RoI-feature gradient / of the feature-map gradients (float or _Float16, see the forward)
+template <class GT, class DT>
 __global__ __launch_bounds__(256) void roialign_bwd_tiles_kernel(RoiLevels L, RoiSets S, RoiTileTable T, int P, int sample_num,
-                                                                 const float* __restrict__ gout, int64_t g_roi_stride,
+                                                                 const GT* __restrict__ gout, int64_t g_roi_stride,
                                                                  const int* __restrict__ offsets, const int* __restrict__ list,
                                                                  const int* __restrict__ lmeta,
                                                                  const float* __restrict__ wtab, int ntiles, int nchunks, int RB_SEGS, int RB_SEG_MIN) {
@@ -668,11 +674,11 @@ __global__ __launch_bounds__(256) void roialign_bwd_tiles_kernel(RoiLevels L, Ro
                 }
                 pw[j] = w;
             }
-            const float* gp = gout + (int64_t)k * g_roi_stride + ((int64_t)s * L.C + c0) * 49;
+            const GT* gp = gout + (int64_t)k * g_roi_stride + ((int64_t)s * L.C + c0) * 49;
 #pragma unroll
             for (int i = 0; i < RB_GPT; ++i) {
                 const int q = tid + 256 * i;
-                if (q < ncc * 49) pg[j][i] = gp[q];
+                if (q < ncc * 49) pg[j][i] = (float)gp[q];
             }
         }
     };
@@ -724,9 +730,9 @@ __global__ __launch_bounds__(256) void roialign_bwd_tiles_kernel(RoiLevels L, Ro
         }
     }
     {
-        float* d = L.dfeat[0];
+        DT* d = (DT*)L.dfeat[0];
 #pragma unroll
-        for (int i = 1; i < ARFE_MAX_LEVELS; ++i) if (i == lvl) d = L.dfeat[i];
+        for (int i = 1; i < ARFE_MAX_LEVELS; ++i) if (i == lvl) d = (DT*)L.dfeat[i];
         const int ox = tx * RT + l15;
 #pragma unroll
         for (int c = 0; c < RB_CPW; ++c) {
@@ -736,9 +742,13 @@ __global__ __launch_bounds__(256) void roialign_bwd_tiles_kernel(RoiLevels L, Ro
             for (int r = 0; r < 4; ++r) {
                 const int oy = ty * RT + 4 * lq + r;
                 if (oy >= H) continue;
-                float* dst = d + (((int64_t)b * L.C + c0 + cc) * H + oy) * W + ox;
-                if (nseg == 1) *dst = acc[c][r];
-                else unsafeAtomicAdd(dst, acc[c][r]);
+                DT* dst = d + (((int64_t)b * L.C + c0 + cc) * H + oy) * W + ox;
+                if constexpr (sizeof(DT) == 4) {
+                    if (nseg == 1) *dst = acc[c][r];
+                    else unsafeAtomicAdd(dst, acc[c][r]);
+                } else {
+                    *dst = (DT)acc[c][r];          // (half maps: the host never slices RoI lists, every tile is stored once)
+                }
             }
         }
     }
@@ -841,10 +851,11 @@ extern "C" int64_t arfe_roialign_fwd_workspace_bytes(int32_t nsets, int32_t R) {
     return (int64_t)nsets * R * ((int64_t)sizeof(RoiWeightHdr) + (int64_t)2 * 7 * RW_EXT * sizeof(float) + 8) + 64;
 }
 
-extern "C" int32_t arfe_roialign_fwd(const arfe_pyramid_t* pyr, const float* const* feats, const int32_t* strides,
-                                     int32_t nsets, int32_t R, const float* const* rois, const int64_t* const* levels,
-                                     int32_t pooled, int32_t sample_num, float* out, int64_t out_roi_stride,
-                                     void* workspace, void* stream) {
+static int32_t roialign_fwd_any(const arfe_pyramid_t* pyr, const void* const* feats_any, const int32_t* strides,
+                                int32_t nsets, int32_t R, const float* const* rois, const int64_t* const* levels,
+                                int32_t pooled, int32_t sample_num, void* out, int64_t out_roi_stride,
+                                void* workspace, void* stream, bool half_io) {
+    const float* const* feats = (const float* const*)feats_any;      // (addresses only: the kernel instantiation knows the type)
     int32_t rc = check_pyramid(pyr);
     if (rc) return rc;
     ARFE_CHECK_ARG(R >= 0 && nsets >= 1 && nsets <= RB_MAXSETS && sample_num >= 0, ARFE_ERR_ARG, "roialign_fwd: bad arguments");
@@ -875,10 +886,30 @@ extern "C" int32_t arfe_roialign_fwd(const arfe_pyramid_t* pyr, const float* con
     hipLaunchKernelGGL(roi_weight_table_kernel, dim3(nroi), dim3(256), 0, st, L, S, pooled, sample_num, hdr, wtab,
                        (const int32_t*)order, 0);
     ARFE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(roialign_fwd_sep_kernel, dim3(nroi * nslices), dim3(256), 0, st, L, S, pooled, sample_num,
-                       (const RoiWeightHdr*)hdr, (const float*)wtab, nslices, out, out_roi_stride);
+    if (half_io)
+        hipLaunchKernelGGL((roialign_fwd_sep_kernel<_Float16, _Float16>), dim3(nroi * nslices), dim3(256), 0, st, L, S, pooled,
+                           sample_num, (const RoiWeightHdr*)hdr, (const float*)wtab, nslices, (_Float16*)out, out_roi_stride);
+    else
+        hipLaunchKernelGGL((roialign_fwd_sep_kernel<float, float>), dim3(nroi * nslices), dim3(256), 0, st, L, S, pooled,
+                           sample_num, (const RoiWeightHdr*)hdr, (const float*)wtab, nslices, (float*)out, out_roi_stride);
     ARFE_CHECK_LAUNCH();
     return ARFE_OK;
+}
+
+extern "C" int32_t arfe_roialign_fwd(const arfe_pyramid_t* pyr, const float* const* feats, const int32_t* strides,
+                                     int32_t nsets, int32_t R, const float* const* rois, const int64_t* const* levels,
+                                     int32_t pooled, int32_t sample_num, float* out, int64_t out_roi_stride,
+                                     void* workspace, void* stream) {
+    return roialign_fwd_any(pyr, (const void* const*)feats, strides, nsets, R, rois, levels, pooled, sample_num, out,
+                            out_roi_stride, workspace, stream, false);
+}
+// half feature maps in, half RoI features out (the extractor of a model in fp16 mode); out_roi_stride in ELEMENTS
+extern "C" int32_t arfe_roialign_fwd_h(const arfe_pyramid_t* pyr, const void* const* feats, const int32_t* strides,
+                                       int32_t nsets, int32_t R, const float* const* rois, const int64_t* const* levels,
+                                       int32_t pooled, int32_t sample_num, void* out, int64_t out_roi_stride,
+                                       void* workspace, void* stream) {
+    return roialign_fwd_any(pyr, feats, strides, nsets, R, rois, levels, pooled, sample_num, out, out_roi_stride, workspace,
+                            stream, true);
 }
 
 static RoiTileTable make_roi_tile_table(const arfe_pyramid_t* pyr, int* ntiles, int* max_tiles_per_img) {
@@ -1023,23 +1054,48 @@ extern "C" int32_t arfe_roialign_bwd_prezero(const arfe_pyramid_t* pyr, float* c
     return ARFE_OK;
 }
 
-extern "C" int32_t arfe_roialign_bwd_apply(const arfe_pyramid_t* pyr, float* const* dfeats, const int32_t* strides,
-                                           int32_t nsets, int32_t R, const float* const* rois, const int64_t* const* levels,
-                                           int32_t pooled, int32_t sample_num, const float* gout, int64_t gout_roi_stride,
-                                           const void* workspace, void* stream) {
+static int32_t roialign_bwd_apply_any(const arfe_pyramid_t* pyr, void* const* dfeats_any, const int32_t* strides,
+                                      int32_t nsets, int32_t R, const float* const* rois, const int64_t* const* levels,
+                                      int32_t pooled, int32_t sample_num, const void* gout, int64_t gout_roi_stride,
+                                      const void* workspace, void* stream, bool half_io) {
     RoiLevels L;
     RoiSets S;
-    int32_t rc = roi_bwd_args(pyr, dfeats, strides, nsets, R, rois, levels, pooled, sample_num, workspace, L, S);
+    int32_t rc = roi_bwd_args(pyr, (float* const*)dfeats_any, strides, nsets, R, rois, levels, pooled, sample_num, workspace, L, S);
     if (rc) return rc;
     ARFE_CHECK_ARG(R == 0 || gout, ARFE_ERR_ARG, "roialign_bwd: null pointer");
     RoiBwdPlan p = plan_roi_bwd(pyr, nsets, R, const_cast<void*>(workspace));
     const int nchunks = cdiv(L.C, RB_CC);
     ARFE_CHECK_ARG((int64_t)p.ntiles * nchunks < (int64_t)1 << 31, ARFE_ERR_ARG, "roialign_bwd: pyramid too large");
-    hipLaunchKernelGGL(roialign_bwd_tiles_kernel, dim3(p.ntiles * nchunks, 1, rb_seg().segs), dim3(256), 0, as_stream(stream), L, S, p.T,
-                       pooled, sample_num, gout, gout_roi_stride, (const int*)p.offsets, (const int*)p.list, (const int*)p.lmeta,
-                       (const float*)p.wtab, p.ntiles, nchunks, rb_seg().segs, rb_seg().seg_min);
+    if (half_io)      // one workgroup per tile and chunk, plain stores (no sliced lists: there is no half atomic path)
+        hipLaunchKernelGGL((roialign_bwd_tiles_kernel<_Float16, _Float16>), dim3(p.ntiles * nchunks, 1, 1), dim3(256), 0,
+                           as_stream(stream), L, S, p.T, pooled, sample_num, (const _Float16*)gout, gout_roi_stride,
+                           (const int*)p.offsets, (const int*)p.list, (const int*)p.lmeta, (const float*)p.wtab, p.ntiles, nchunks,
+                           1, 1 << 30);
+    else
+        hipLaunchKernelGGL((roialign_bwd_tiles_kernel<float, float>), dim3(p.ntiles * nchunks, 1, rb_seg().segs), dim3(256), 0,
+                           as_stream(stream), L, S, p.T, pooled, sample_num, (const float*)gout, gout_roi_stride,
+                           (const int*)p.offsets, (const int*)p.list, (const int*)p.lmeta, (const float*)p.wtab, p.ntiles, nchunks,
+                           rb_seg().segs, rb_seg().seg_min);
     ARFE_CHECK_LAUNCH();
     return ARFE_OK;
+}
+
+extern "C" int32_t arfe_roialign_bwd_apply(const arfe_pyramid_t* pyr, float* const* dfeats, const int32_t* strides,
+                                           int32_t nsets, int32_t R, const float* const* rois, const int64_t* const* levels,
+                                           int32_t pooled, int32_t sample_num, const float* gout, int64_t gout_roi_stride,
+                                           const void* workspace, void* stream) {
+    return roialign_bwd_apply_any(pyr, (void* const*)dfeats, strides, nsets, R, rois, levels, pooled, sample_num, gout,
+                                  gout_roi_stride, workspace, stream, false);
+}
+// half gradients in, half feature-map gradients out, on a workspace prepared by arfe_roialign_bwd_prepare (every element of
+// dfeats is written; gout_roi_stride in ELEMENTS)
+extern "C" int32_t arfe_roialign_bwd_prepared_h(const arfe_pyramid_t* pyr, void* const* dfeats, const int32_t* strides,
+                                                int32_t nsets, int32_t R, const float* const* rois,
+                                                const int64_t* const* levels, int32_t pooled, int32_t sample_num,
+                                                const void* gout, int64_t gout_roi_stride, const void* workspace,
+                                                void* stream) {
+    return roialign_bwd_apply_any(pyr, dfeats, strides, nsets, R, rois, levels, pooled, sample_num, gout, gout_roi_stride,
+                                  workspace, stream, true);
 }
 
 extern "C" int32_t arfe_roialign_bwd_prepared(const arfe_pyramid_t* pyr, float* const* dfeats, const int32_t* strides,

@@ -390,15 +390,18 @@ def _stride_array(strides):
 
 
 def roialign_fwd_op(feats, strides, roi_sets, level_sets, out, pooled=7, sample_num=0):
-    """RoIAlign of every set into its channel slice of `out` [R, nsets*C, 7, 7] (one launch for all sets)."""
-    hip.require_f32_cuda(*feats, *roi_sets, out)
+    """RoIAlign of every set into its channel slice of `out` [R, nsets*C, 7, 7] (one launch for all sets).
+    Half feature maps + a half `out` take the half-storage instantiation (fp16 mode)."""
+    half = feats[0].dtype == torch.float16
+    hip.require_cuda(torch.float16 if half else torch.float32, *feats, out)
+    hip.require_f32_cuda(*roi_sets)
     pyr = Pyramid.of(feats, 0)
     nsets, R = len(roi_sets), roi_sets[0].shape[0]
     ws = _ws(hip.lib().arfe_roialign_fwd_workspace_bytes(nsets, R), out.device)
+    fn = hip.lib().arfe_roialign_fwd_h if half else hip.lib().arfe_roialign_fwd
     with probe('roialign_fwd'):
-        check(hip.lib().arfe_roialign_fwd(ctypes.byref(pyr), ptr_array(feats), _stride_array(strides), nsets, R,
-                                          ptr_array(roi_sets), ptr_array(level_sets), pooled, sample_num, ptr(out),
-                                          out.stride(0), ptr(ws), stream()), "arfe_roialign_fwd")
+        check(fn(ctypes.byref(pyr), ptr_array(feats), _stride_array(strides), nsets, R, ptr_array(roi_sets),
+                 ptr_array(level_sets), pooled, sample_num, ptr(out), out.stride(0), ptr(ws), stream()), "arfe_roialign_fwd")
 
 
 def roialign_bwd_prepare_op(feats, strides, roi_sets, level_sets, pooled=7, sample_num=0):
@@ -431,6 +434,20 @@ def roialign_bwd_op(shapes, strides, roi_sets, level_sets, gout, pooled=7, sampl
     prezeroed: the dfeats of roialign_bwd_prezero_op (same prepared workspace, ordered before the current stream)."""
     dev = gout.device
     nsets, R = len(roi_sets), roi_sets[0].shape[0]
+    if gout.dtype == torch.float16:          # fp16 mode: half gradient in, half feature-map gradients out
+        dfeats = [torch.empty(shape, dtype=torch.float16, device=dev) for shape in shapes]
+        pyr = Pyramid.of(dfeats, 0)
+        if prepared is None:
+            prepared = _ws(hip.lib().arfe_roialign_bwd_workspace_bytes(ctypes.byref(pyr), nsets, R), dev)
+            check(hip.lib().arfe_roialign_bwd_prepare(ctypes.byref(pyr), _stride_array(strides), nsets, R, ptr_array(roi_sets),
+                                                      ptr_array(level_sets), pooled, sample_num, ptr(prepared), stream()),
+                  "arfe_roialign_bwd_prepare")
+        with probe('roialign_bwd'):
+            check(hip.lib().arfe_roialign_bwd_prepared_h(ctypes.byref(pyr), ptr_array(dfeats), _stride_array(strides), nsets, R,
+                                                         ptr_array(roi_sets), ptr_array(level_sets), pooled, sample_num,
+                                                         ptr(gout), gout.stride(0), ptr(prepared), stream()),
+                  "arfe_roialign_bwd_prepared_h")
+        return dfeats
     if prezeroed is not None:
         dfeats = list(prezeroed)
         pyr = Pyramid.of(dfeats, 0)
@@ -468,7 +485,7 @@ class RoIExtractFunction(torch.autograd.Function):
         feats = [f.contiguous() for f in t[nsets + nl:]]
         R, C = roi_sets[0].shape[0], feats[0].shape[1]
         dev = feats[0].device
-        out = torch.empty(R, nsets * C, pooled, pooled, device=dev)
+        out = torch.empty(R, nsets * C, pooled, pooled, device=dev, dtype=feats[0].dtype)      # (half maps -> half features)
         if have_levels:
             levels = [l.contiguous() for l in t[nsets:nsets + nl]]
         else:
@@ -1012,6 +1029,54 @@ class CastFunction(torch.autograd.Function):
         return _cast_op(g, not ctx.to_half), None
 
 
+def _cast_multi_op(ts, to_half):
+    """one launch for a list of contiguous GPU tensors -> list of converted tensors"""
+    ts = [t.contiguous() for t in ts]
+    want = torch.float32 if to_half else torch.float16
+    for t in ts:
+        if not t.is_cuda or t.dtype != want:
+            raise hip.ArfeHipError(f"cast expects {want} GPU tensors, got {t.dtype} on {t.device}")
+    outs = [torch.empty(t.shape, dtype=torch.float16 if to_half else torch.float32, device=t.device) for t in ts]
+    k = len(ts)
+    if k == 0:
+        return outs
+    src = (ctypes.c_void_p * k)(*[t.data_ptr() for t in ts])
+    dst = (ctypes.c_void_p * k)(*[o.data_ptr() for o in outs])
+    n = (ctypes.c_int64 * k)(*[t.numel() for t in ts])
+    check(hip.lib().arfe_cast_multi(k, src, dst, n, int(to_half), stream()), "arfe_cast_multi")
+    return outs
+
+
+class MultiCastFunction(torch.autograd.Function):
+    """cast_tensor_type over a LIST of tensors in one launch each way (the parameters of a module in fp16 mode)."""
+
+    @staticmethod
+    def forward(ctx, to_half, *ts):
+        ctx.to_half = to_half
+        return tuple(_cast_multi_op(ts, to_half))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        idx = [i for i, g in enumerate(gs) if g is not None]
+        conv = _cast_multi_op([gs[i] for i in idx], not ctx.to_half)
+        out = [None] * len(gs)
+        for i, c in zip(idx, conv):
+            out[i] = c
+        return (None, *out)
+
+
+def to_f32_list(ts):
+    """[half tensors] -> [float tensors], one launch (float entries pass through)."""
+    ts = list(ts)
+    idx = [i for i, t in enumerate(ts) if t is not None and t.dtype == torch.float16]
+    if len(idx) <= 1:
+        return [to_f32(t) for t in ts]
+    conv = MultiCastFunction.apply(False, *[ts[i] for i in idx])
+    for i, c in zip(idx, conv):
+        ts[i] = c
+    return ts
+
+
 def to_f32(t):
     """half -> float through the library (float tensors pass through)."""
     if t is None or t.dtype == torch.float32:
@@ -1050,4 +1115,4 @@ def f32_boundary(tensors, params, what):
         return to_f16(out)
     # half storage = the reference's fp16 mode: the module's contractions take half operands (pass finish.half_ops on)
     finish.half_ops = os.environ.get('ARFE_FP16_F32_PRODUCTS', '0') != '1'
-    return [to_f32(t) for t in tensors], [to_f32(p) for p in params], finish
+    return [to_f32(t) for t in tensors], to_f32_list(params), finish

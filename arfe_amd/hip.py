@@ -61,6 +61,8 @@ SIGNATURES = {
     "arfe_rff_roi_sets": (_i32, [_i32, _vp, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "arfe_roialign_fwd_workspace_bytes": (_i64, [_i32, _i32]),
     "arfe_roialign_fwd": (_i32, [_PP, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp]),
+    "arfe_roialign_fwd_h": (_i32, [_PP, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp]),
+    "arfe_roialign_bwd_prepared_h": (_i32, [_PP, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp]),
     "arfe_roialign_bwd_workspace_bytes": (_i64, [_PP, _i32, _i32]),
     "arfe_roialign_bwd": (_i32, [_PP, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp]),
     "arfe_roialign_bwd_prepare": (_i32, [_PP, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp]),
@@ -87,6 +89,7 @@ SIGNATURES = {
     "arfe_nearest_add_fwd": (_i32, [_i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp]),
     "arfe_nearest_add_bwd": (_i32, [_i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp]),
     "arfe_subsample2": (_i32, [_i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
+    "arfe_cast_multi": (_i32, [_i32, _vp, _vp, _vp, _i32, _vp]),
     "arfe_cast_f16_to_f32": (_i32, [_i64, _vp, _vp, _vp]),
     "arfe_cast_f32_to_f16": (_i32, [_i64, _vp, _vp, _vp]),
 }
@@ -137,6 +140,15 @@ def ptr_array(tensors):
 
 def stream():
     return torch.cuda.current_stream().cuda_stream
+
+
+def require_cuda(dtype, *tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not (t.is_cuda and t.dtype == dtype and t.is_contiguous()):
+            raise ArfeHipError(f"expected a contiguous {dtype} tensor on the GPU, got {t.dtype} {t.device} "
+                               f"contiguous={t.is_contiguous()}")
 
 
 def require_f32_cuda(*tensors):

@@ -80,10 +80,21 @@ class SingleRoIExtractor(nn.Module):
         fp32 inside and half out in fp16 mode, like `forward` (single_level.py:109)."""
         return self._extract(feats, roi_sets)
 
-    @force_fp32(apply_to=('feats', ), out_fp16=True)
     def extract_ar_sets(self, feats, rois):
         """The AR-RFF body of `_bbox_forward` (standard_roi_head.py:138-155): get_adaptive_scale_rois(rois, 1), the level
-        of every RoI of the three sets (one launch for both) and the [ori, lw, lh] channel concat."""
+        of every RoI of the three sets (one launch for both) and the [ori, lw, lh] channel concat.
+        fp16 mode (single_level.py:109 @force_fp32(apply_to=('feats',), out_fp16=True)): half maps in, half features out.
+        The kernels read / write half storage directly and compute in fp32 - the values of the decorator's
+        half -> float -> RoIAlign -> half chain without its two conversion passes over the pyramid."""
+        feats = list(feats)[:self.num_inputs]
+        if self.fp16_enabled and all(f.is_cuda and f.dtype == torch.float16 for f in feats):
+            rois = rois.float().contiguous()
+            lh_rois, lw_rois, (lv_ori, lv_w, lv_h) = Fn.rff_roi_sets_op(rois, len(feats), self.finest_scale)
+            return self._extract(feats, [rois, lw_rois, lh_rois], [lv_ori, lv_w, lv_h])
+        return self._extract_ar_sets_f32(feats, rois)
+
+    @force_fp32(apply_to=('feats', ), out_fp16=True)
+    def _extract_ar_sets_f32(self, feats, rois):
         feats = list(feats)[:self.num_inputs]
         rois = rois.float().contiguous()
         lh_rois, lw_rois, (lv_ori, lv_w, lv_h) = Fn.rff_roi_sets_op(rois, len(feats), self.finest_scale)

@@ -177,6 +177,20 @@ int32_t arfe_roialign_fwd(const arfe_pyramid_t* pyr, const float* const* feats, 
                           int32_t pooled, int32_t sample_num, float* out, int64_t out_roi_stride,
                           void* workspace, void* stream);
 
+/* The same forward with HALF feature maps and a HALF output (the extractor of a model in the reference's fp16 mode reads
+ * the half maps a neck handed on and returns half RoI features, single_level.py:109 @force_fp32(out_fp16=True)): the kernel
+ * converts on load / store, the arithmetic is the fp32 one - results equal a half -> float pass, arfe_roialign_fwd and a float ->
+ * half pass.  out_roi_stride in elements. */
+int32_t arfe_roialign_fwd_h(const arfe_pyramid_t* pyr, const void* const* feats, const int32_t* strides, int32_t nsets,
+                            int32_t R, const float* const* rois, const int64_t* const* levels, int32_t pooled,
+                            int32_t sample_num, void* out, int64_t out_roi_stride, void* workspace, void* stream);
+/* ... and its backward on a workspace filled by arfe_roialign_bwd_prepare: half gradient in, half feature-map gradients out
+ * (every element written). */
+int32_t arfe_roialign_bwd_prepared_h(const arfe_pyramid_t* pyr, void* const* dfeats, const int32_t* strides, int32_t nsets,
+                                     int32_t R, const float* const* rois, const int64_t* const* levels, int32_t pooled,
+                                     int32_t sample_num, const void* gout, int64_t gout_roi_stride, const void* workspace,
+                                     void* stream);
+
 /* dfeats[i] = sum over all `nsets` RoI sets of RoIAlign^T(gout slice of that set): every element of every
  * dfeats[i] is written by the call (a 16x16 tile whose RoI list is long is zeroed and summed by a few workgroups
  * with float atomics, every other tile - the empty ones included - is stored exactly once).  Set s reads its upstream
@@ -282,6 +296,11 @@ int32_t arfe_nearest_add_bwd(int32_t B, int32_t C, int32_t h, int32_t w, float* 
                              const float* dlat, void* stream);
 /* backward == 0: out[B,C,(H-1)/2+1,(W-1)/2+1] = in[B,C,H,W][::2, ::2]; backward != 0: out[B,C,H,W] = scatter of in */
 int32_t arfe_subsample2(int32_t B, int32_t C, int32_t H, int32_t W, const float* in, float* out, int32_t backward,
+                        void* stream);
+
+/* `count` tensors converted by one launch (to_half: fp32 -> half, else half -> fp32); src[i] / dst[i] hold n[i] elements.  The
+ * three arrays are HOST arrays read at launch time.  Same rounding as the single-tensor forms below. */
+int32_t arfe_cast_multi(int32_t count, const void* const* src, void* const* dst, const int64_t* n, int32_t to_half,
                         void* stream);
 
 /* ---- fp16 mode: mmdet/core/fp16/utils.py:7-23 cast_tensor_type ------------------------------------

@@ -53,7 +53,10 @@ def test_argument_errors_do_not_touch_the_gpu():
     assert l.arfe_map_roi_levels(4, None, 6, 56.0, None, None) == -1      # num_levels > 5
     assert l.arfe_linear_fwd(-1, 4, 4, None, None, None, 0, None, None, 0, None) == -1
     assert l.arfe_linear_workspace_bytes(1024, 12544, 1024) == (256 << 20) + 64 and l.arfe_linear_workspace_bytes(-1, 4, 4) == -1
-    assert l.arfe_conv3x3_packed_bytes(256) == 4 * 9 * 256 * 256 * 4      # fwd + dgrad layouts, as packed words and as bf16 planes
+    assert l.arfe_conv3x3_packed_bytes(256) == 5 * 9 * 256 * 256 * 4      # fwd + dgrad layouts: packed words, bf16 (hi | lo) planes, half planes
+    assert l.arfe_set_operand_precision(2) == -1 and l.arfe_set_operand_precision(1) == 0 and l.arfe_get_operand_precision() == 1
+    assert l.arfe_set_operand_precision(0) == 0 and l.arfe_get_operand_precision() == 0
+    assert l.arfe_cast_multi(1, None, None, None, 0, None) == -1 and l.arfe_cast_multi(0, None, None, None, 0, None) == 0
     assert l.arfe_conv3x3_workspace_bytes(256) == 32 * 9 * 256 * 256 * 4   # 32 row-slice slabs of the stage-once weight gradient
     assert l.arfe_conv3x3_workspace_bytes(20) == 9 * 20 * 20 * 4
     assert l.arfe_nonlocal_workspace_bytes(2, 256, 4200) > 0
