@@ -65,6 +65,10 @@ int32_t check_pyramid(const arfe_pyramid_t* p) {
         set_error("refine_level=%d outside [0,%d)", p->refine_level, p->num_levels);
         return ARFE_ERR_ARG;
     }
+    if (p->storage != ARFE_STORAGE_F32 && p->storage != ARFE_STORAGE_F16) {
+        set_error("pyramid storage=%d (0 = fp32, 1 = half)", p->storage);
+        return ARFE_ERR_ARG;
+    }
     if (p->batch < 1 || p->channels < 1) {
         set_error("batch=%d channels=%d must be positive", p->batch, p->channels);
         return ARFE_ERR_ARG;

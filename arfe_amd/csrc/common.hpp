@@ -89,6 +89,7 @@ struct Levels {
     //   sh > 0: level is finer  (H = Hr << sh)   sh < 0: coarser (Hr = H << -sh)   sh == 0: same size
     //   SH_GENERAL: no such ratio -> kernels take the generic index path (ragged / unpadded pyramids)
     int sh[ARFE_MAX_LEVELS];
+    int half;     // the per-level activation arrays hold IEEE halves (arfe_pyramid_t::storage)
 };
 constexpr int SH_GENERAL = 99;
 static inline int pow2_shift(int big, int small) {   // big == small << s ? s : -1
@@ -98,6 +99,7 @@ static inline int pow2_shift(int big, int small) {   // big == small << s ? s : 
 static inline Levels to_levels(const arfe_pyramid_t* p) {
     Levels l;
     l.n = p->num_levels; l.r = p->refine_level; l.B = p->batch; l.C = p->channels;
+    l.half = p->storage == ARFE_STORAGE_F16 ? 1 : 0;
     for (int i = 0; i < ARFE_MAX_LEVELS; ++i) { l.H[i] = p->height[i]; l.W[i] = p->width[i]; l.sh[i] = SH_GENERAL; }
     const int hr = p->height[l.r], wr = p->width[l.r];
     for (int i = 0; i < l.n; ++i) {

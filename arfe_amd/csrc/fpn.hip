@@ -10,6 +10,14 @@ constexpr int NL_ = ARFE_MAX_LEVELS;
 struct LevelPtrs { const float* p[NL_]; };
 struct LevelMutPtrs { float* p[NL_]; };
 
+// activation storage (arfe_pyramid_t::storage): fp32 or IEEE half, converted on load
+typedef _Float16 half4_v __attribute__((ext_vector_type(4), aligned(2)));
+__device__ __forceinline__ float4_u ld4(const float* p) { return *reinterpret_cast<const float4_u*>(p); }
+__device__ __forceinline__ float4_u ld4(const _Float16* p) {
+    const half4_v h = *reinterpret_cast<const half4_v*>(p);
+    return float4_u{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+}
+
 // =========================================================================================================
 // gather:  m[b,c,py,px] = (sum_i G_i) / n ; one thread per refine-level element, lanes along px
 // =========================================================================================================
@@ -481,7 +489,7 @@ __global__ __launch_bounds__(256) void fpn_scatter_bwd_dbsf_kernel(Levels lv, Le
 // Instantiated for NF = 0, 1, 2 finer levels whose size ratio to the refine level is exactly 2^(r - i); other pyramids
 // (ragged sizes, refine level 3 or 4) keep the two-kernel form.
 // =========================================================================================================
-template <int NF>
+template <int NF, class T>
 __global__ __launch_bounds__(256) void fpn_scatter_bwd_fused_kernel(Levels lv, LevelPtrs gout, const float* __restrict__ bsf,
                                                                     LevelPtrs a, LevelPtrs b, LevelMutPtrs dpa,
                                                                     float* __restrict__ dbsf) {
@@ -564,31 +572,31 @@ __global__ __launch_bounds__(256) void fpn_scatter_bwd_fused_kernel(Levels lv, L
         u = bsf[bc * plane_r + s];
         if constexpr (NF >= 1) {
             const int w = lv.W[0];
-            const float* gp = gout.p[0] + bc * (int64_t)lv.H[0] * w + o0;
+            const T* gp = (const T*)gout.p[0] + bc * (int64_t)lv.H[0] * w + o0;
 #pragma unroll
             for (int yy = 0; yy < W0; ++yy) {
                 if constexpr (W0 == 4) {
-                    const float4_u v = *reinterpret_cast<const float4_u*>(gp + yy * w);
+                    const float4_u v = ld4(gp + yy * w);
                     g0[yy * 4 + 0] = v[0]; g0[yy * 4 + 1] = v[1]; g0[yy * 4 + 2] = v[2]; g0[yy * 4 + 3] = v[3];
                 } else {
 #pragma unroll
-                    for (int xx = 0; xx < W0; ++xx) g0[yy * W0 + xx] = gp[yy * w + xx];
+                    for (int xx = 0; xx < W0; ++xx) g0[yy * W0 + xx] = (float)gp[yy * w + xx];
                 }
             }
         }
         if constexpr (NF >= 2) {
             const int w = lv.W[1];
-            const float* gp = gout.p[1] + bc * (int64_t)lv.H[1] * w + o1;
+            const T* gp = (const T*)gout.p[1] + bc * (int64_t)lv.H[1] * w + o1;
 #pragma unroll
             for (int yy = 0; yy < W1; ++yy)
 #pragma unroll
-                for (int xx = 0; xx < W1; ++xx) g1[yy * W1 + xx] = gp[yy * w + xx];
+                for (int xx = 0; xx < W1; ++xx) g1[yy * W1 + xx] = (float)gp[yy * w + xx];
         }
 #pragma unroll
         for (int k = 0; k < NC; ++k) {
             const int i = NF + k;
             gc[k] = 0.f;
-            if (i < lv.n && vc[k]) gc[k] = gout.p[i][bc * (int64_t)lv.H[i] * lv.W[i] + oc[k]];
+            if (i < lv.n && vc[k]) gc[k] = (float)((const T*)gout.p[i])[bc * (int64_t)lv.H[i] * lv.W[i] + oc[k]];
         }
     };
     auto fold = [&](int c, const float (&g0)[W0 * W0], const float (&g1)[W1 * W1], const float (&gc)[NC], float u) {
@@ -971,6 +979,7 @@ __global__ void fpn_gate_wgrad_zero_kernel(int C, int n, LevelMutPtrs dw1, Level
     if (i < n * per) { const int l = i / per, j = i - l * per; dw1.p[l][j] = 0.f; dw2.p[l][j] = 0.f; }
     if (i < n) { db1.p[i][0] = 0.f; db2.p[i][0] = 0.f; }
 }
+template <class T>
 __global__ __launch_bounds__(256) void fpn_gate_wgrad_mfma_kernel(Levels lv, TileTable tt, LevelPtrs x, LevelPtrs dpa,
                                                                   LevelPtrs dpb, LevelMutPtrs dw1, LevelMutPtrs db1,
                                                                   LevelMutPtrs dw2, LevelMutPtrs db2) {
@@ -984,7 +993,7 @@ __global__ __launch_bounds__(256) void fpn_gate_wgrad_mfma_kernel(Levels lv, Til
     const int chunk = t - bi * tt.tiles_x[lvl];
     const int cg0 = blockIdx.y * GW_CH;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
-    const float* xb = x.p[lvl] + (int64_t)bi * lv.C * hw;
+    const T* xb = (const T*)x.p[lvl] + (int64_t)bi * lv.C * hw;
     const float* da = dpa.p[lvl] + (int64_t)bi * hw;
     const float* db = dpb.p[lvl] + (int64_t)bi * hw;
     const int px_begin = chunk * (GW_PX * GW_STAGES);
@@ -1008,12 +1017,12 @@ __global__ __launch_bounds__(256) void fpn_gate_wgrad_mfma_kernel(Levels lv, Til
 #pragma unroll
         for (int ps = 0; ps < 8; ++ps) {
             const int c = cg0 + ps * 32 + xc;
-            const float* src = xb + (int64_t)(c < lv.C ? c : lv.C - 1) * hw;
+            const T* src = xb + (int64_t)(c < lv.C ? c : lv.C - 1) * hw;
             if (p + 3 < hw) {
-                xr[ps] = *reinterpret_cast<const float4_u*>(src + p);
+                xr[ps] = ld4(src + p);
             } else {       // the map's last pixels: clamped element reads (their D entries are zero)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) xr[ps][e] = src[p + e < hw ? p + e : hw - 1];
+                for (int e = 0; e < 4; ++e) xr[ps][e] = (float)src[p + e < hw ? p + e : hw - 1];
             }
         }
     };
@@ -1172,6 +1181,7 @@ extern "C" int32_t arfe_fpn_gather_fwd(const arfe_pyramid_t* pyr, const float* c
     Levels lv = to_levels(pyr);
     LevelPtrs xp;
     ARFE_CHECK_ARG(fill_ptrs(xp, x, lv.n) && m, ARFE_ERR_ARG, "fpn_gather_fwd: null pointer");
+    ARFE_CHECK_ARG(!lv.half, ARFE_ERR_ARG, "fpn_gather_fwd: fp32 storage only (half pyramids: arfe_fpn_gather_gate_fwd)");
     const int64_t total = (int64_t)lv.B * lv.C * lv.H[lv.r] * lv.W[lv.r];
     hipLaunchKernelGGL(fpn_gather_fwd_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, as_stream(stream), lv, xp,
                        m, argmax);
@@ -1191,6 +1201,7 @@ extern "C" int32_t arfe_fpn_gatemap_fwd(const arfe_pyramid_t* pyr, const float* 
                        fill_ptrs(b1p, b1, lv.n) && fill_ptrs(b2p, b2, lv.n) && fill_ptrs(ap, a, lv.n) &&
                        fill_ptrs(bp, b, lv.n) && workspace,
                    ARFE_ERR_ARG, "fpn_gatemap_fwd: null pointer");
+    ARFE_CHECK_ARG(!lv.half, ARFE_ERR_ARG, "fpn_gatemap_fwd: fp32 storage only (half pyramids: arfe_fpn_gather_gate_fwd)");
     TileTable tt = make_tile_table(lv);
     const int64_t pre_total = tt.px_off[lv.n];
     float* pre = (float*)workspace;
@@ -1210,6 +1221,23 @@ extern "C" int32_t arfe_fpn_gatemap_fwd(const arfe_pyramid_t* pyr, const float* 
 // gather + gate maps in one call (round 3): when the pyramid is eligible the fused kernel reads x ONCE for both
 // (fpn_stream.hip); otherwise the two first-generation ops run one after the other.  Results are those of
 // arfe_fpn_gather_fwd + arfe_fpn_gatemap_fwd (m and argmax bit-identical).
+// which pyramids have half-storage instantiations of EVERY AR-FPN kernel (the conditions of the second-generation kernels and
+// of the single-pass scatter backward)
+extern "C" int32_t arfe_fpn_half_storage_supported(const arfe_pyramid_t* pyr) {
+    if (check_pyramid(pyr)) return 0;
+    const Levels lv = to_levels(pyr);
+    static const bool v2_off = []() { const char* e = getenv("ARFE_FPN_V2"); return e && e[0] == '0'; }();
+    static const char* sw = getenv("ARFE_FPN_BWD_FUSED");
+    if (v2_off || (sw && sw[0] == '0')) return 0;
+    if (lv.r > 2 || lv.C < 4) return 0;
+    if ((int64_t)lv.B * lv.C * lv.H[lv.r] * lv.W[lv.r] * 4 >= ((int64_t)1 << 31)) return 0;
+    for (int i = 0; i < lv.n; ++i) {
+        if ((int64_t)lv.B * lv.C * lv.H[i] * lv.W[i] * 4 >= ((int64_t)1 << 31)) return 0;
+        if (i < lv.r && (lv.sh[i] != lv.r - i || (lv.W[i] & 3) != 0)) return 0;    // pooled levels: ratio 4 / 2, whole quads
+    }
+    return 1;
+}
+
 extern "C" int64_t arfe_fpn_gather_gate_workspace_bytes(const arfe_pyramid_t* pyr) {
     const int64_t base = arfe_fpn_gatemap_workspace_bytes(pyr);
     if (base < 0) return base;
@@ -1238,6 +1266,7 @@ extern "C" int32_t arfe_fpn_gather_gate_fwd(const arfe_pyramid_t* pyr, const flo
     const int32_t done = fpn_gather_gate_v2(lv, x, w1, w2, m, argmax, Gbuf, pre, st);
     if (done < 0) return done;
     if (!done) {
+        ARFE_CHECK_ARG(!lv.half, ARFE_ERR_ARG, "fpn_gather_gate_fwd: this pyramid has no half-storage kernels (arfe_fpn_half_storage_supported)");
         rc = arfe_fpn_gather_fwd(pyr, x, m, argmax, stream);
         if (rc) return rc;
         return arfe_fpn_gatemap_fwd(pyr, x, w1, b1, w2, b2, a, b, workspace, stream);
@@ -1262,6 +1291,7 @@ extern "C" int32_t arfe_fpn_scatter_fwd(const arfe_pyramid_t* pyr, const float* 
         const int32_t done = fpn_scatter_fwd_v2(lv, x, bsf, a, b, out, as_stream(stream));      // round 3 (fpn_stream.hip)
         if (done) return done < 0 ? done : ARFE_OK;
     }
+    ARFE_CHECK_ARG(!lv.half, ARFE_ERR_ARG, "fpn_scatter_fwd: this pyramid has no half-storage kernels (arfe_fpn_half_storage_supported)");
     BlockQuadTable bt;
     int nblk = 0;
     for (int i = 0; i <= NL_; ++i) {
@@ -1305,9 +1335,13 @@ extern "C" int32_t arfe_fpn_scatter_bwd(const arfe_pyramid_t* pyr, const float* 
             const int npx = lv.H[lv.r] * lv.W[lv.r];
             const int nchunk = lv.C >= 128 ? 4 : (lv.C >= 32 ? 2 : 1);
             dim3 grid((unsigned)(cdiv(npx, 64) * lv.B), nchunk);
-            if (lv.r == 2) hipLaunchKernelGGL((fpn_scatter_bwd_fused_kernel<2>), grid, dim3(256), 0, st, lv, gp, bsf, ap, bp, dap, dbsf);
-            else if (lv.r == 1) hipLaunchKernelGGL((fpn_scatter_bwd_fused_kernel<1>), grid, dim3(256), 0, st, lv, gp, bsf, ap, bp, dap, dbsf);
-            else hipLaunchKernelGGL((fpn_scatter_bwd_fused_kernel<0>), grid, dim3(256), 0, st, lv, gp, bsf, ap, bp, dap, dbsf);
+#define ARFE_SBF(NF)                                                                                                            \
+    if (lv.half) hipLaunchKernelGGL((fpn_scatter_bwd_fused_kernel<NF, _Float16>), grid, dim3(256), 0, st, lv, gp, bsf, ap, bp, dap, dbsf); \
+    else hipLaunchKernelGGL((fpn_scatter_bwd_fused_kernel<NF, float>), grid, dim3(256), 0, st, lv, gp, bsf, ap, bp, dap, dbsf);
+            if (lv.r == 2) { ARFE_SBF(2) }
+            else if (lv.r == 1) { ARFE_SBF(1) }
+            else { ARFE_SBF(0) }
+#undef ARFE_SBF
             ARFE_CHECK_LAUNCH();
             TileTable tt = make_tile_table(lv);
             hipLaunchKernelGGL(fpn_scatter_bwd_maps_finish_kernel, dim3((unsigned)cdiv64(tt.px_off[lv.n], 256)), dim3(256), 0, st,
@@ -1316,6 +1350,7 @@ extern "C" int32_t arfe_fpn_scatter_bwd(const arfe_pyramid_t* pyr, const float* 
             return ARFE_OK;
         }
     }
+    ARFE_CHECK_ARG(!lv.half, ARFE_ERR_ARG, "fpn_scatter_bwd: this pyramid has no half-storage kernels (arfe_fpn_half_storage_supported)");
     PixQuadTable pt = make_pixquad_table(lv);
     const int nchunk = lv.C >= 64 ? 4 : 1;
     if (nchunk > 1) {
@@ -1356,6 +1391,8 @@ extern "C" int32_t arfe_fpn_input_bwd(const arfe_pyramid_t* pyr, const float* co
     // levels, ratios above 4) goes through the first-generation kernels below
     const int32_t done = fpn_input_bwd_v2(lv, gout, dpre_a, dpre_b, w1, w2, dm, argmax, dx, as_stream(stream));
     if (done < 0) return done;
+    ARFE_CHECK_ARG(!lv.half || done == (1 << lv.n) - 1, ARFE_ERR_ARG,
+                   "fpn_input_bwd: this pyramid has no half-storage kernels (arfe_fpn_half_storage_supported)");
     // levels with an exact power-of-two ratio to the refine level take the shift-only kernel, the rest (e.g. the
     // 13x21 top level of the 1333x800 pyramid, 25 -> 13 by a ceil) the generic one: two launches over disjoint levels
     for (int pass = 0; pass < 3; ++pass) {
@@ -1407,8 +1444,12 @@ extern "C" int32_t arfe_fpn_gate_wgrad(const arfe_pyramid_t* pyr, const float* c
                        lv.n, w1p, b1p, w2p, b2p);
     ARFE_CHECK_LAUNCH();
     TileTable tt = make_tile_table(lv, GW_PX * GW_STAGES);
-    hipLaunchKernelGGL(fpn_gate_wgrad_mfma_kernel, dim3(tt.first_tile[lv.n], cdiv(lv.C, GW_CH)), dim3(256), 0,
-                       as_stream(stream), lv, tt, xp, dap, dbp, w1p, b1p, w2p, b2p);
+    if (lv.half)
+        hipLaunchKernelGGL(fpn_gate_wgrad_mfma_kernel<_Float16>, dim3(tt.first_tile[lv.n], cdiv(lv.C, GW_CH)), dim3(256), 0,
+                           as_stream(stream), lv, tt, xp, dap, dbp, w1p, b1p, w2p, b2p);
+    else
+        hipLaunchKernelGGL(fpn_gate_wgrad_mfma_kernel<float>, dim3(tt.first_tile[lv.n], cdiv(lv.C, GW_CH)), dim3(256), 0,
+                           as_stream(stream), lv, tt, xp, dap, dbp, w1p, b1p, w2p, b2p);
     ARFE_CHECK_LAUNCH();
     return ARFE_OK;
 }

@@ -78,6 +78,30 @@ __device__ __forceinline__ void store_quad(float* __restrict__ p, const Item& it
     if (it.x0 + 2 < w) p[2] = v[2];
     if (it.x0 + 3 < w) p[3] = v[3];
 }
+// half storage (arfe_pyramid_t::storage == ARFE_STORAGE_F16): 8-byte accesses, converted on the way (round to nearest even on
+// the way out, as Tensor.half())
+typedef _Float16 half4_u __attribute__((ext_vector_type(4), aligned(2)));
+template <bool WIDE>
+__device__ __forceinline__ float4_u load_quad(const _Float16* __restrict__ p, const Item& it) {
+    if constexpr (WIDE) {
+        const half4_u h = *reinterpret_cast<const half4_u*>(p);
+        return float4_u{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+    }
+    float4_u v = {(float)p[0], (float)p[it.e1], (float)p[it.e2], (float)p[it.e3]};
+    return v;
+}
+template <bool WIDE>
+__device__ __forceinline__ void store_quad(_Float16* __restrict__ p, const Item& it, int w, const float4_u v) {
+    if constexpr (WIDE) {
+        const half4_u h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+        *reinterpret_cast<half4_u*>(p) = h;
+        return;
+    }
+    p[0] = (_Float16)v[0];
+    if (it.x0 + 1 < w) p[1] = (_Float16)v[1];
+    if (it.x0 + 2 < w) p[2] = (_Float16)v[2];
+    if (it.x0 + 3 < w) p[3] = (_Float16)v[3];
+}
 
 // =========================================================================================================
 // backward C, v2:  dx = g + conv3x3^T(dpre_a; w1) + conv3x3^T(dpre_b; w2) + gather^T(dm / n)
@@ -113,12 +137,12 @@ constexpr int IB_ROWS_SH2 = ARFE_IB_ROWS_SH2, IB_ROWS_SH1 = ARFE_IB_ROWS_SH1;   
 // the 18 scalar weights: 2.5 / 4 vector-memory instructions per (quad, channel) instead of 4 / 6 (the streaming kernels run
 // at ~35 cycles per vector-memory instruction and CU, see fpn_scatter_fwd2).  The items of such a level are (image, row
 // group, quad column); the channel-independent neighbourhood is the (ROWS + 2) x 6 patch of the two gradient maps.
-template <int MODE, bool WIDE, int ROWS>
+template <int MODE, bool WIDE, int ROWS, class T>
 __device__ __forceinline__ void input_bwd2_level(const Levels& lv, const ItemTable& tb, int lvl, int blk, int lane, int cw,
-                                                 const float* __restrict__ g, const float* __restrict__ da,
+                                                 const T* __restrict__ g, const float* __restrict__ da,
                                                  const float* __restrict__ db, const float* w1, const float* w2,
                                                  const float* __restrict__ dm, const int32_t* __restrict__ argmax,
-                                                 float* __restrict__ dx) {
+                                                 T* __restrict__ dx) {
     static_assert(ROWS == 1 || MODE == IB_SH2 || MODE == IB_SH1, "row groups are pooling windows");
     constexpr int SH = MODE == IB_SH2 ? 2 : (MODE == IB_SH1 ? 1 : 0);
     const int h = lv.H[lvl], w = lv.W[lvl], wq = tb.wq[lvl];
@@ -299,6 +323,7 @@ __device__ __forceinline__ void input_bwd2_level(const Levels& lv, const ItemTab
     }
 }
 
+template <class T>
 __global__ __launch_bounds__(256, ARFE_IB_WAVES) void fpn_input_bwd2_kernel(Levels lv, ItemTable tb, SLevelPtrs gout, SLevelPtrs dpa,
                                                              SLevelPtrs dpb, SLevelPtrs w1, SLevelPtrs w2,
                                                              const float* __restrict__ dm, const int32_t* __restrict__ argmax,
@@ -317,20 +342,20 @@ __global__ __launch_bounds__(256, ARFE_IB_WAVES) void fpn_input_bwd2_kernel(Leve
     const int nwork = tb.nwork[lvl];
     const int blk = (j & 7) * ((nwork + 7) >> 3) + (j >> 3);
     if (blk >= nwork) return;
-    const float* g = gout.p[lvl];
+    const T* g = (const T*)gout.p[lvl];
     const float* da = dpa.p[lvl];
     const float* db = dpb.p[lvl];
-    float* d = dx.p[lvl];
+    T* d = (T*)dx.p[lvl];
     const bool wide = (lv.W[lvl] & 3) == 0;
 #define ARFE_IB2(M, R)                                                                                                     \
-    if (wide) input_bwd2_level<M, true, R>(lv, tb, lvl, blk, lane, cw, g, da, db, w1.p[lvl], w2.p[lvl], dm, argmax, d);  \
-    else input_bwd2_level<M, false, 1>(lv, tb, lvl, blk, lane, cw, g, da, db, w1.p[lvl], w2.p[lvl], dm, argmax, d);
+    if (wide) input_bwd2_level<M, true, R, T>(lv, tb, lvl, blk, lane, cw, g, da, db, w1.p[lvl], w2.p[lvl], dm, argmax, d);  \
+    else input_bwd2_level<M, false, 1, T>(lv, tb, lvl, blk, lane, cw, g, da, db, w1.p[lvl], w2.p[lvl], dm, argmax, d);
     switch (tb.mode[lvl]) {
         case IB_SH2: ARFE_IB2(IB_SH2, IB_ROWS_SH2) break;
         case IB_SH1: ARFE_IB2(IB_SH1, IB_ROWS_SH1) break;
         case IB_SH0: ARFE_IB2(IB_SH0, 1) break;
-        case IB_SHM1: input_bwd2_level<IB_SHM1, false, 1>(lv, tb, lvl, blk, lane, cw, g, da, db, w1.p[lvl], w2.p[lvl], dm, argmax, d); break;
-        default: input_bwd2_level<IB_GEN, false, 1>(lv, tb, lvl, blk, lane, cw, g, da, db, w1.p[lvl], w2.p[lvl], dm, argmax, d); break;
+        case IB_SHM1: input_bwd2_level<IB_SHM1, false, 1, T>(lv, tb, lvl, blk, lane, cw, g, da, db, w1.p[lvl], w2.p[lvl], dm, argmax, d); break;
+        default: input_bwd2_level<IB_GEN, false, 1, T>(lv, tb, lvl, blk, lane, cw, g, da, db, w1.p[lvl], w2.p[lvl], dm, argmax, d); break;
     }
 #undef ARFE_IB2
 }
@@ -346,11 +371,11 @@ __global__ __launch_bounds__(256, ARFE_IB_WAVES) void fpn_input_bwd2_kernel(Leve
 typedef float float2_u __attribute__((ext_vector_type(2), aligned(4)));
 constexpr int SC2_CPW = 16, SC2_U = 4;
 
-template <int MODE, bool WIDE>
+template <int MODE, bool WIDE, class T>
 __device__ __forceinline__ void scatter2_level(const Levels& lv, const ItemTable& tb, int lvl, int blk, int lane, int cw,
-                                               const float* __restrict__ x, const float* __restrict__ bsf,
+                                               const T* __restrict__ x, const float* __restrict__ bsf,
                                                const float* __restrict__ a, const float* __restrict__ b,
-                                               float* __restrict__ out) {
+                                               T* __restrict__ out) {
     const int h = lv.H[lvl], w = lv.W[lvl], wq = tb.wq[lvl];
     const int hr = lv.H[lv.r], wr = lv.W[lv.r];
     const int cgroups = tb.cgroups[lvl], cpw = tb.cpw[lvl];
@@ -416,6 +441,7 @@ __device__ __forceinline__ void scatter2_level(const Levels& lv, const ItemTable
     }
 }
 
+template <class T>
 __global__ __launch_bounds__(256) void fpn_scatter_fwd2_kernel(Levels lv, ItemTable tb, SLevelPtrs x, const float* __restrict__ bsf,
                                                                SLevelPtrs a, SLevelPtrs b, SLevelMutPtrs out) {
     const int lane = threadIdx.x & 63, cw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -427,13 +453,13 @@ __global__ __launch_bounds__(256) void fpn_scatter_fwd2_kernel(Levels lv, ItemTa
     if (blk >= nwork) return;
     const bool wide = (lv.W[lvl] & 3) == 0;
 #define ARFE_SC2(M)                                                                                                 \
-    if (wide) scatter2_level<M, true>(lv, tb, lvl, blk, lane, cw, x.p[lvl], bsf, a.p[lvl], b.p[lvl], out.p[lvl]);   \
-    else scatter2_level<M, false>(lv, tb, lvl, blk, lane, cw, x.p[lvl], bsf, a.p[lvl], b.p[lvl], out.p[lvl]);
+    if (wide) scatter2_level<M, true, T>(lv, tb, lvl, blk, lane, cw, (const T*)x.p[lvl], bsf, a.p[lvl], b.p[lvl], (T*)out.p[lvl]);   \
+    else scatter2_level<M, false, T>(lv, tb, lvl, blk, lane, cw, (const T*)x.p[lvl], bsf, a.p[lvl], b.p[lvl], (T*)out.p[lvl]);
     switch (tb.mode[lvl]) {
         case IB_SH2: ARFE_SC2(IB_SH2) break;
         case IB_SH1: ARFE_SC2(IB_SH1) break;
         case IB_SH0: ARFE_SC2(IB_SH0) break;
-        default: scatter2_level<IB_GEN, false>(lv, tb, lvl, blk, lane, cw, x.p[lvl], bsf, a.p[lvl], b.p[lvl], out.p[lvl]); break;
+        default: scatter2_level<IB_GEN, false, T>(lv, tb, lvl, blk, lane, cw, (const T*)x.p[lvl], bsf, a.p[lvl], b.p[lvl], (T*)out.p[lvl]); break;
     }
 #undef ARFE_SC2
 }
@@ -488,10 +514,10 @@ struct GGTable {
     int64_t px_off[NLS + 1];   // prefix sum of B*h*w: offset of a level inside T
 };
 
-template <int LR, bool WIDE>
+template <int LR, bool WIDE, class T>
 __device__ __forceinline__ void gather_gate_level(const Levels& lv, const GGTable& tb, int lvl, int blk, int lane, int cw,
-                                                  const float* __restrict__ x, const float* w1, const float* w2,
-                                                  float* __restrict__ G, int32_t* __restrict__ argmax, float* __restrict__ T,
+                                                  const T* __restrict__ x, const float* w1, const float* w2,
+                                                  float* __restrict__ G, int32_t* __restrict__ argmax, float* __restrict__ Tm,
                                                   float* red) {
     const int h = lv.H[lvl], w = lv.W[lvl], wq = tb.wq[lvl];
     const int hr = lv.H[lv.r], wr = lv.W[lv.r];
@@ -581,7 +607,7 @@ __device__ __forceinline__ void gather_gate_level(const Levels& lv, const GGTabl
         }
     }
     // ---- channel quarters -> T: two halves (gate 1, gate 2) of 36 values per lane through LDS, summed wave 0..3 ----
-    float* Tb = T + tb.px_off[lvl] * GG_M + (size_t)it.bi * GG_M * plane + (size_t)(it.y * w + it.x0);
+    float* Tb = Tm + tb.px_off[lvl] * GG_M + (size_t)it.bi * GG_M * plane + (size_t)(it.y * w + it.x0);
 #pragma unroll
     for (int gate = 0; gate < 2; ++gate) {
         if (gate) __syncthreads();
@@ -609,9 +635,10 @@ __device__ __forceinline__ void gather_gate_level(const Levels& lv, const GGTabl
     }
 }
 
+template <class T>
 __global__ __launch_bounds__(64 * GG_NW, ARFE_GG_WAVES) void fpn_gather_gate_kernel(Levels lv, GGTable tb, SLevelPtrs x, SLevelPtrs w1, SLevelPtrs w2,
                                                               SLevelMutPtrs G, int32_t* __restrict__ argmax,
-                                                              float* __restrict__ T) {
+                                                              float* __restrict__ Tm) {
     __shared__ float red[GG_NW * 9 * 4 * 64];              // 36 KB at 4 waves: [wave][tap][pixel][lane]
     const int lane = threadIdx.x & 63, cw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int lvl = lv.n - 1;
@@ -623,19 +650,20 @@ __global__ __launch_bounds__(64 * GG_NW, ARFE_GG_WAVES) void fpn_gather_gate_ker
     const size_t am_off = (size_t)lvl * lv.B * lv.C * lv.H[lv.r] * lv.W[lv.r];
     int32_t* am = argmax ? argmax + am_off : nullptr;
     switch (tb.lr[lvl]) {
-        case 2: gather_gate_level<2, true>(lv, tb, lvl, blk, lane, cw, x.p[lvl], w1.p[lvl], w2.p[lvl], G.p[lvl], am, T, red); break;
-        case 1: gather_gate_level<1, true>(lv, tb, lvl, blk, lane, cw, x.p[lvl], w1.p[lvl], w2.p[lvl], G.p[lvl], am, T, red); break;
+        case 2: gather_gate_level<2, true, T>(lv, tb, lvl, blk, lane, cw, (const T*)x.p[lvl], w1.p[lvl], w2.p[lvl], G.p[lvl], am, Tm, red); break;
+        case 1: gather_gate_level<1, true, T>(lv, tb, lvl, blk, lane, cw, (const T*)x.p[lvl], w1.p[lvl], w2.p[lvl], G.p[lvl], am, Tm, red); break;
         default:
             if ((lv.W[lvl] & 3) == 0)
-                gather_gate_level<0, true>(lv, tb, lvl, blk, lane, cw, x.p[lvl], w1.p[lvl], w2.p[lvl], nullptr, nullptr, T, red);
+                gather_gate_level<0, true, T>(lv, tb, lvl, blk, lane, cw, (const T*)x.p[lvl], w1.p[lvl], w2.p[lvl], nullptr, nullptr, Tm, red);
             else
-                gather_gate_level<0, false>(lv, tb, lvl, blk, lane, cw, x.p[lvl], w1.p[lvl], w2.p[lvl], nullptr, nullptr, T, red);
+                gather_gate_level<0, false, T>(lv, tb, lvl, blk, lane, cw, (const T*)x.p[lvl], w1.p[lvl], w2.p[lvl], nullptr, nullptr, Tm, red);
             break;
     }
 }
 
 // m = (((((0 + G_0) + G_1) + ...) + G_{n-1}) / n over the refine-sized maps: pooled levels from G, the others from x through
 // the nearest index (exactly the first-generation kernel's arithmetic: the result is bit-identical)
+template <class T>
 __global__ __launch_bounds__(256) void fpn_gather_mean_kernel(Levels lv, SLevelPtrs x, SLevelPtrs G, float* __restrict__ m) {
     // one thread per 4 consecutive pixels of a refine-level row (16-byte accesses where the row allows)
     const int hr = lv.H[lv.r], wr = lv.W[lv.r], wqr = (wr + 3) >> 2;
@@ -651,8 +679,8 @@ __global__ __launch_bounds__(256) void fpn_gather_mean_kernel(Levels lv, SLevelP
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int i = 0; i < lv.n; ++i) {
         float g[4];
-        if (i < lv.r || lv.sh[i] == 0) {
-            const float* src = (i < lv.r ? G.p[i] : x.p[i]) + o;
+        if (i < lv.r) {
+            const float* src = G.p[i] + o;
             if (full) {
                 const float4_u v = *reinterpret_cast<const float4_u*>(src);
                 g[0] = v[0]; g[1] = v[1]; g[2] = v[2]; g[3] = v[3];
@@ -660,13 +688,17 @@ __global__ __launch_bounds__(256) void fpn_gather_mean_kernel(Levels lv, SLevelP
 #pragma unroll
                 for (int e = 0; e < 4; ++e) g[e] = src[px0 + e < wr ? e : 0];
             }
+        } else if (lv.sh[i] == 0) {
+            const T* src = (const T*)x.p[i] + o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = (float)src[px0 + e < wr ? e : 0];
         } else {
             const int h = lv.H[i], w = lv.W[i];
             const int sy = nearest_src(py, h, nearest_scale(h, hr));
             const float xs = nearest_scale(w, wr);
-            const float* srow = x.p[i] + ((size_t)bc * h + sy) * w;
+            const T* srow = (const T*)x.p[i] + ((size_t)bc * h + sy) * w;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) g[e] = srow[nearest_src(px0 + e < wr ? px0 + e : wr - 1, w, xs)];
+            for (int e = 0; e < 4; ++e) g[e] = (float)srow[nearest_src(px0 + e < wr ? px0 + e : wr - 1, w, xs)];
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[e] = acc[e] + g[e];
@@ -716,10 +748,12 @@ int32_t fpn_gather_gate_v2(const Levels& lv, const float* const* x, const float*
     }
     for (int i = lv.n; i <= NLS; ++i) tb.first_blk[i] = 0;
     tb.first_blk[NLS] = nblk;
-    hipLaunchKernelGGL(fpn_gather_gate_kernel, dim3(nblk), dim3(64 * GG_NW), 0, stream, lv, tb, xp, w1p, w2p, gm, argmax, T);
+    if (lv.half) hipLaunchKernelGGL(fpn_gather_gate_kernel<_Float16>, dim3(nblk), dim3(64 * GG_NW), 0, stream, lv, tb, xp, w1p, w2p, gm, argmax, T);
+    else hipLaunchKernelGGL(fpn_gather_gate_kernel<float>, dim3(nblk), dim3(64 * GG_NW), 0, stream, lv, tb, xp, w1p, w2p, gm, argmax, T);
     if (hipGetLastError() != hipSuccess) { set_error("fpn_gather_gate launch failed"); return ARFE_ERR_LAUNCH; }
     const int64_t mquads = (int64_t)lv.B * lv.C * lv.H[lv.r] * cdiv(lv.W[lv.r], 4);
-    hipLaunchKernelGGL(fpn_gather_mean_kernel, dim3((unsigned)cdiv64(mquads, 256)), dim3(256), 0, stream, lv, xp, gp, m);
+    if (lv.half) hipLaunchKernelGGL(fpn_gather_mean_kernel<_Float16>, dim3((unsigned)cdiv64(mquads, 256)), dim3(256), 0, stream, lv, xp, gp, m);
+    else hipLaunchKernelGGL(fpn_gather_mean_kernel<float>, dim3((unsigned)cdiv64(mquads, 256)), dim3(256), 0, stream, lv, xp, gp, m);
     if (hipGetLastError() != hipSuccess) { set_error("fpn_gather_mean launch failed"); return ARFE_ERR_LAUNCH; }
     return 1;
 }
@@ -790,8 +824,12 @@ int32_t fpn_input_bwd_v2(const Levels& lv, const float* const* gout, const float
     for (int i = lv.n; i <= NLS; ++i) tb.first_blk[i] = 0;
     tb.first_blk[NLS] = nblk;
     if (nblk == 0) return 0;
-    hipLaunchKernelGGL(fpn_input_bwd2_kernel, dim3(nblk), dim3(256), 0, stream, lv, tb, gp, ap, bp, w1p, w2p, dm,
-                       argmax, dxp);
+    if (lv.half)
+        hipLaunchKernelGGL(fpn_input_bwd2_kernel<_Float16>, dim3(nblk), dim3(256), 0, stream, lv, tb, gp, ap, bp, w1p, w2p, dm,
+                           argmax, dxp);
+    else
+        hipLaunchKernelGGL(fpn_input_bwd2_kernel<float>, dim3(nblk), dim3(256), 0, stream, lv, tb, gp, ap, bp, w1p, w2p, dm,
+                           argmax, dxp);
     if (hipGetLastError() != hipSuccess) { set_error("fpn_input_bwd2 launch failed"); return ARFE_ERR_LAUNCH; }
     return mask;
 }
@@ -827,7 +865,8 @@ int32_t fpn_scatter_fwd_v2(const Levels& lv, const float* const* x, const float*
     }
     for (int i = lv.n; i <= NLS; ++i) tb.first_blk[i] = 0;
     tb.first_blk[NLS] = nblk;
-    hipLaunchKernelGGL(fpn_scatter_fwd2_kernel, dim3(nblk), dim3(256), 0, stream, lv, tb, xp, bsf, ap, bp, op);
+    if (lv.half) hipLaunchKernelGGL(fpn_scatter_fwd2_kernel<_Float16>, dim3(nblk), dim3(256), 0, stream, lv, tb, xp, bsf, ap, bp, op);
+    else hipLaunchKernelGGL(fpn_scatter_fwd2_kernel<float>, dim3(nblk), dim3(256), 0, stream, lv, tb, xp, bsf, ap, bp, op);
     if (hipGetLastError() != hipSuccess) { set_error("fpn_scatter_fwd2 launch failed"); return ARFE_ERR_LAUNCH; }
     return 1;
 }

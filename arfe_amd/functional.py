@@ -127,6 +127,20 @@ def join_side(device):
 # AR-FPN raw ops
 # ---------------------------------------------------------------------------------------------------------
 
+def _req_levels(xs):
+    """pyramid levels: contiguous GPU tensors of ONE storage dtype, fp32 or (fp16 mode, eligible pyramids) half"""
+    dt = xs[0].dtype
+    if dt not in (torch.float32, torch.float16):
+        raise hip.ArfeHipError(f"pyramid levels must be fp32 or half, got {dt}")
+    hip.require_cuda(dt, *xs)
+
+
+def fpn_half_storage_supported(xs, refine_level):
+    """True when every AR-FPN kernel has a half-storage instantiation for this pyramid (arfe_fpn_half_storage_supported)."""
+    pyr = Pyramid.of(xs, refine_level)
+    return bool(hip.lib().arfe_fpn_half_storage_supported(ctypes.byref(pyr)))
+
+
 def fpn_gather_op(xs, refine_level, want_argmax=True):
     hip.require_f32_cuda(*xs)
     pyr = Pyramid.of(xs, refine_level)
@@ -158,7 +172,8 @@ def fpn_gatemap_op(xs, w1, b1, w2, b2, refine_level=0):
 
 def fpn_gather_gate_op(xs, w1, b1, w2, b2, refine_level, want_argmax=True):
     """-> (m, argmax, a, b): gather and both gate maps from ONE read of the pyramid (arfe_fpn_gather_gate_fwd)."""
-    hip.require_f32_cuda(*xs, *w1, *b1, *w2, *b2)
+    _req_levels(xs)
+    hip.require_f32_cuda(*w1, *b1, *w2, *b2)
     pyr = Pyramid.of(xs, refine_level)
     B, C = xs[0].shape[:2]
     hr, wr = xs[refine_level].shape[2:]
@@ -178,7 +193,8 @@ def fpn_gather_gate_op(xs, w1, b1, w2, b2, refine_level, want_argmax=True):
 
 
 def fpn_scatter_op(xs, bsf, a, b, refine_level):
-    hip.require_f32_cuda(*xs, bsf, *a, *b)
+    _req_levels(xs)
+    hip.require_f32_cuda(bsf, *a, *b)
     pyr = Pyramid.of(xs, refine_level)
     outs = _empty_like_levels(xs)
     with probe('fpn_scatter_fwd'):
@@ -188,7 +204,8 @@ def fpn_scatter_op(xs, bsf, a, b, refine_level):
 
 
 def fpn_scatter_bwd_op(gouts, bsf, a, b, refine_level):
-    hip.require_f32_cuda(*gouts, bsf, *a, *b)
+    _req_levels(gouts)
+    hip.require_f32_cuda(bsf, *a, *b)
     pyr = Pyramid.of(gouts, refine_level)
     dpa = [torch.empty_like(t) for t in a]
     dpb = [torch.empty_like(t) for t in b]
@@ -201,7 +218,8 @@ def fpn_scatter_bwd_op(gouts, bsf, a, b, refine_level):
 
 
 def fpn_input_bwd_op(gouts, dpa, dpb, w1, w2, dm, argmax, refine_level):
-    hip.require_f32_cuda(*gouts, *dpa, *dpb, *w1, *w2, dm)
+    _req_levels(gouts)
+    hip.require_f32_cuda(*dpa, *dpb, *w1, *w2, dm)
     pyr = Pyramid.of(gouts, refine_level)
     dxs = _empty_like_levels(gouts)
     with probe('fpn_input_bwd'):
@@ -212,7 +230,8 @@ def fpn_input_bwd_op(gouts, dpa, dpb, w1, w2, dm, argmax, refine_level):
 
 
 def fpn_gate_wgrad_op(xs, dpa, dpb, refine_level=0):
-    hip.require_f32_cuda(*xs, *dpa, *dpb)
+    _req_levels(xs)
+    hip.require_f32_cuda(*dpa, *dpb)
     pyr = Pyramid.of(xs, refine_level)
     dev, C = xs[0].device, xs[0].shape[1]
     n = len(xs)

@@ -19,7 +19,7 @@ _i32, _i64, _vp, _f32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.
 
 class Pyramid(ctypes.Structure):
     _fields_ = [("num_levels", _i32), ("refine_level", _i32), ("batch", _i32), ("channels", _i32),
-                ("height", _i32 * MAX_LEVELS), ("width", _i32 * MAX_LEVELS)]
+                ("height", _i32 * MAX_LEVELS), ("width", _i32 * MAX_LEVELS), ("storage", _i32)]
 
     @staticmethod
     def of(tensors, refine_level=0):
@@ -28,6 +28,7 @@ class Pyramid(ctypes.Structure):
         p.num_levels = len(tensors)
         p.refine_level = refine_level
         p.batch, p.channels = tensors[0].shape[0], tensors[0].shape[1]
+        p.storage = 1 if tensors[0].dtype == torch.float16 else 0      # what the per-level activation arrays hold
         for i, t in enumerate(tensors):
             assert t.shape[0] == p.batch and t.shape[1] == p.channels, "levels disagree on batch/channels"
             p.height[i], p.width[i] = t.shape[2], t.shape[3]
@@ -41,6 +42,7 @@ SIGNATURES = {
     "arfe_abi_version": (_i32, []),
     "arfe_set_operand_precision": (_i32, [_i32]),
     "arfe_get_operand_precision": (_i32, []),
+    "arfe_fpn_half_storage_supported": (_i32, [_PP]),
     "arfe_fpn_gather_fwd": (_i32, [_PP, _vp, _vp, _vp, _vp]),
     "arfe_fpn_gatemap_workspace_bytes": (_i64, [_PP]),
     "arfe_fpn_gatemap_fwd": (_i32, [_PP, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

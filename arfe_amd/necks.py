@@ -1,5 +1,6 @@
 """AR-FPN: `WFPNDualSpatial` with the constructor, registry name and state_dict keys of the reference
 (mmdet/models/necks/wfpn_dual_spatial.py:10-137); forward/backward run in libarfe_hip."""
+import torch
 import torch.nn as nn
 
 from . import functional as Fn
@@ -39,9 +40,18 @@ class WFPNDualSpatial(nn.Module):
         b1 = [m.conv.bias for m in self.reduce_convs]
         w2 = [m.conv.weight for m in self.reduce_convs2]
         b2 = [m.conv.bias for m in self.reduce_convs2]
-        # fp16 mode (wrap_fp16_model): half storage, fp32 inside the library
+        # fp16 mode (wrap_fp16_model): half storage, fp32 arithmetic inside the library
         n = self.num_levels
-        xs, p, finish = Fn.f32_boundary(inputs, w1 + b1 + w2 + b2 + list(self.refine.hip_params()), 'WFPNDualSpatial')
+        params = w1 + b1 + w2 + b2 + list(self.refine.hip_params())
+        inputs = list(inputs)
+        if (Fn.storage_dtype(inputs, params, 'WFPNDualSpatial') == torch.float16 and all(t.is_cuda for t in inputs)
+                and Fn.fpn_half_storage_supported([t.contiguous() for t in inputs], self.refine_level)):
+            # the streaming kernels read and write the half pyramid themselves (half the bytes, no conversion passes); only
+            # the parameters are converted (one launch)
+            p = Fn.to_f32_list(params)
+            return tuple(Fn.arfpn(inputs, p[:n], p[n:2 * n], p[2 * n:3 * n], p[3 * n:4 * n], *p[4 * n:],
+                                  refine_level=self.refine_level, half_ops=True))
+        xs, p, finish = Fn.f32_boundary(inputs, params, 'WFPNDualSpatial')
         return finish(tuple(Fn.arfpn(xs, p[:n], p[n:2 * n], p[2 * n:3 * n], p[3 * n:4 * n], *p[4 * n:],
                                      refine_level=self.refine_level, half_ops=finish.half_ops)))
 

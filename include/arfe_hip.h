@@ -40,7 +40,16 @@ typedef struct arfe_pyramid {
     int32_t channels;
     int32_t height[ARFE_MAX_LEVELS];
     int32_t width[ARFE_MAX_LEVELS];
+    int32_t storage;       /* ARFE_STORAGE_F32 (0) or ARFE_STORAGE_F16: what the PER-LEVEL activation arrays of the AR-FPN entry
+                            * points (x, out, gout, dx) hold.  With F16 (the reference's fp16 mode: a half pyramid in, a half
+                            * pyramid out) those pointers address IEEE halves - pass them through a cast - and the kernels
+                            * convert on load / store; every other tensor (gate maps, m, bsf, dm, weights, gradients of the
+                            * weights) stays fp32 and so does the arithmetic.  arfe_fpn_half_storage_supported says whether a
+                            * pyramid's kernels have half instantiations (otherwise the caller converts, as in round 2). */
 } arfe_pyramid_t;
+#define ARFE_STORAGE_F32 0
+#define ARFE_STORAGE_F16 1
+int32_t arfe_fpn_half_storage_supported(const arfe_pyramid_t* pyr);
 
 const char* arfe_last_error(void);
 int32_t arfe_abi_version(void);

@@ -954,6 +954,53 @@ def test_half_operand_mode_is_exact_for_half_values(Fn, dev, R):
     assert relerr(y3, y_ref.detach().float()) <= TOL
 
 
+@pytest.mark.parametrize('shape,C', [('mid', 12), ('bench', 8), ('tiny', 8), ('ragged', 8)])
+def test_arfpn_half_storage_equals_the_conversion_route(Fn, O, dev, shape, C):
+    """fp16 mode of the neck: on eligible pyramids the streaming kernels read / write the half pyramid themselves
+    (arfe_pyramid_t::storage = F16).  The arithmetic is the fp32 one, so outputs and input gradients must equal, bit for bit,
+    the round-2 route (half -> float pass, fp32 kernels, float -> half pass); parameter gradients (fp32 either way) too."""
+    sizes = O.PYRAMID_1333x800 if shape == 'bench' else PYRAMIDS[shape]
+    g = torch.Generator().manual_seed(13)
+    xs_h = [torch.randn(2, C, h, w, generator=g).half().to(dev) for h, w in sizes]
+    assert Fn.fpn_half_storage_supported(xs_h, 2) == (shape != 'ragged')     # 'ragged': pooled levels that are not 4x / 2x the refine level
+    p = {k: v.half().float().to(dev) for k, v in O.arfpn_params(C, 5, seed=3).items()}
+    cots = [torch.randn(2, C, h, w, generator=g).half().to(dev) for h, w in sizes]
+
+    def run(native):
+        xs = [x.clone().requires_grad_(True) for x in xs_h]
+        pp = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+        w1 = [pp[f'reduce_convs.{i}.conv.weight'] for i in range(5)]
+        b1 = [pp[f'reduce_convs.{i}.conv.bias'] for i in range(5)]
+        w2 = [pp[f'reduce_convs2.{i}.conv.weight'] for i in range(5)]
+        b2 = [pp[f'reduce_convs2.{i}.conv.bias'] for i in range(5)]
+        nl = []
+        for n in ('theta', 'phi', 'g', 'conv_out'):
+            nl += [pp[f'refine.{n}.conv.weight'].view(C, C), pp[f'refine.{n}.conv.bias']]
+        if native:
+            outs = Fn.arfpn(xs, w1, b1, w2, b2, *nl, refine_level=2, half_ops=True)
+        else:
+            outs = [Fn.to_f16(o) for o in Fn.arfpn([Fn.to_f32(x) for x in xs], w1, b1, w2, b2, *nl, refine_level=2, half_ops=True)]
+        assert all(o.dtype == torch.float16 for o in outs)
+        torch.autograd.backward(list(outs), cots)
+        return outs, [x.grad for x in xs], {k: v.grad for k, v in pp.items()}
+
+    if shape == 'ragged':
+        with pytest.raises(Exception):
+            run(True)                     # not eligible: the library refuses half storage (the module converts instead)
+        return
+    o1, dx1, dp1 = run(True)
+    o2, dx2, dp2 = run(False)
+    for a, b in zip(o1, o2):
+        assert torch.equal(a, b)
+    for a, b in zip(dx1, dx2):
+        assert a.dtype == torch.float16 and torch.equal(a, b)
+    for k in dp1:
+        if k == 'refine.phi.conv.bias':
+            continue
+        # (the gate-conv weight gradients are summed with float atomics: equal up to their order)
+        assert relerr(dp1[k], dp2[k]) <= 1e-5, k
+
+
 def test_cast_kernels_match_tensor_to(Fn, dev):
     """arfe_cast_*: round to nearest even, inf/nan/subnormals, unaligned views and ragged tails like Tensor.to."""
     g = torch.Generator().manual_seed(5)
