@@ -123,6 +123,18 @@ def join_side(device):
     torch.cuda.current_stream().wait_stream(side_stream(device))
 
 
+def side_reads(device, *tensors):
+    """Tensors allocated on the CURRENT stream that kernels already enqueued on the side stream still read after the caller
+    returns (a backward that leaves its weight gradients running, join=False): `record_stream` tells the caching allocator
+    not to hand their blocks out again before the side stream has passed this point.  This replaces the rule "hold a `keep`
+    tuple until the next join" that every such caller had to remember (the tuples stay: they cost nothing)."""
+    side = side_stream(device)
+    for t in tensors:
+        if t is not None and t.is_cuda:
+            t.record_stream(side)
+    return tensors
+
+
 # ---------------------------------------------------------------------------------------------------------
 # AR-FPN raw ops
 # ---------------------------------------------------------------------------------------------------------
@@ -296,7 +308,8 @@ def nonlocal_bwd_op(dbsf, m, wt, wp, wg, wo, saved, split_streams=False):
     on_side(dev, lambda: check(L_.arfe_nonlocal_bwd_wcat(B, C, L, ptr(m), ptr(dwt), ptr(dbt), ptr(dwp), ptr(dbp), ptr(dwg),
                                                          ptr(dbg), ptr(ws), stream()), "arfe_nonlocal_bwd_wcat"))
     # (ws, dP and the outputs were allocated on the current stream and are used on the side stream: the caller's join
-    # orders every later use; `keep` holds them until then)
+    # orders every later use; record_stream keeps the allocator from re-issuing them before the side stream is through)
+    side_reads(dev, ws, dP, dbsf, y, m, dwt, dbt, dwp, dbp, dwg, dbg, dwo, dbo)
     return dm, (dwt, dbt, dwp, dbp, dwg, dbg, dwo, dbo), (ws, dP)
 
 
@@ -760,6 +773,8 @@ def _rff_head_backward(saved, dcls, dreg, join=True, defer_gate_wgrads=False, si
     # (dz2, dz, dlw, dlh, ws are read by side-stream kernels that may still be queued when join=False: they were allocated
     # on the current stream, whose allocator only re-issues them to work enqueued after the caller's join)
     keep = (dz2, dz, dlw, dlh, ws, df1, df2, dycr)
+    if not join:
+        side_reads(dev, *keep, x, z, z2f, f1, f2)
     if defer_gate_wgrads:
         return dx, pg, keep, gate_wgrads
     return dx, pg, keep

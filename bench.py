@@ -78,6 +78,7 @@ def parse():
     ap.add_argument('--rois-per-img', type=int, default=512)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-iters', type=int, default=5)
+    ap.add_argument('--no-fp16-leg', action='store_true', help='skip the second (fp16 mode) leg of the default run')
     ap.add_argument('--fp16', action='store_true',
                     help="the reference's fp16 mode (wrap_fp16_model): half storage at module boundaries, fp32 kernels")
     return ap.parse_args()
@@ -236,37 +237,45 @@ def main():
     from arfe_amd.dist import GradAllReducer
     from arfe_amd import synth as O          # synthetic inputs; oracle/ is imported by the cpu_baseline leg only
 
-    neck, roi_head = build_modules(dev)
-    neck_state = {k: v.detach().cpu().clone() for k, v in neck.state_dict().items()}
-    head_state = {k: v.detach().cpu().clone() for k, v in roi_head.bbox_head.state_dict().items()}
-    B, R = args.batch, args.batch * args.rois_per_img
-    xs = [x.to(dev) for x in O.synth_pyramid(B, 256, seed=1234 + rank)]
-    if args.fp16:                                   # SURVEY 8(d) fp16 variant: same tensors .half()
-        import arfe_amd
-        arfe_amd.wrap_fp16_model(neck)
-        arfe_amd.wrap_fp16_model(roi_head)
-        xs = [x.half() for x in xs]
-    xs = [x.requires_grad_(True) for x in xs]
-    rois = O.synth_rois(B, args.rois_per_img, seed=1234 + rank).to(dev)
-    g = torch.Generator().manual_seed(99 + rank)
-    cot_cls = torch.randn(R, 81, generator=g).to(dev)
-    cot_reg = torch.randn(R, 320, generator=g).to(dev)
-    if args.fp16:
-        cot_cls, cot_reg = cot_cls.half(), cot_reg.half()
-    # gradients become ready head-first, then the neck
-    # fc1's weight gradient (51 of the head's 64 MB) exists 2 ms before the step ends: it goes on the wire from the kernel
-    # that produces it instead of with the rest of the head's bucket
-    reducer = GradAllReducer([list(roi_head.bbox_head.parameters()), list(neck.parameters())],
-                             early=[roi_head.bbox_head.shared_fcs[0].weight])
+    def build_workload(fp16):
+        """modules + synthetic inputs + the step closure of one precision mode"""
+        neck, roi_head = build_modules(dev)
+        neck_state = {k: v.detach().cpu().clone() for k, v in neck.state_dict().items()}
+        head_state = {k: v.detach().cpu().clone() for k, v in roi_head.bbox_head.state_dict().items()}
+        xs = [x.to(dev) for x in O.synth_pyramid(B, 256, seed=1234 + rank)]
+        if fp16:                                        # SURVEY 8(d) fp16 variant: same tensors .half()
+            import arfe_amd
+            arfe_amd.wrap_fp16_model(neck)
+            arfe_amd.wrap_fp16_model(roi_head)
+            xs = [x.half() for x in xs]
+        xs = [x.requires_grad_(True) for x in xs]
+        rois = O.synth_rois(B, args.rois_per_img, seed=1234 + rank).to(dev)
+        g = torch.Generator().manual_seed(99 + rank)
+        cot_cls = torch.randn(R, 81, generator=g).to(dev)
+        cot_reg = torch.randn(R, 320, generator=g).to(dev)
+        if fp16:
+            cot_cls, cot_reg = cot_cls.half(), cot_reg.half()
+        # gradients become ready head-first, then the neck
+        # fc1's weight gradient (51 of the head's 64 MB) exists 2 ms before the step ends: it goes on the wire from the kernel
+        # that produces it instead of with the rest of the head's bucket
+        reducer = GradAllReducer([list(roi_head.bbox_head.parameters()), list(neck.parameters())],
+                                 early=[roi_head.bbox_head.shared_fcs[0].weight])
 
-    def step():
-        reducer.zero_grad()
-        for x in xs:
-            x.grad = None
-        feats = neck(xs)
-        res = roi_head._bbox_forward(feats, rois)
-        torch.autograd.backward([res['cls_score'], res['bbox_pred']], [cot_cls, cot_reg])
-        reducer.synchronize()
+        def step():
+            reducer.zero_grad()
+            for x in xs:
+                x.grad = None
+            feats = neck(xs)
+            res = roi_head._bbox_forward(feats, rois)
+            torch.autograd.backward([res['cls_score'], res['bbox_pred']], [cot_cls, cot_reg])
+            reducer.synchronize()
+        return dict(step=step, neck=neck, roi_head=roi_head, xs=xs, rois=rois, cot_cls=cot_cls, cot_reg=cot_reg,
+                    neck_state=neck_state, head_state=head_state, reducer=reducer)
+
+    B, R = args.batch, args.batch * args.rois_per_img
+    wl = build_workload(args.fp16)
+    step, neck, roi_head, xs, rois = wl['step'], wl['neck'], wl['roi_head'], wl['xs'], wl['rois']
+    cot_cls, cot_reg, neck_state, head_state = wl['cot_cls'], wl['cot_reg'], wl['neck_state'], wl['head_state']
 
     def fence():
         torch.cuda.synchronize()
@@ -297,6 +306,26 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
+
+    # second leg (N = 1, default flags only): the SAME step in the reference's fp16 mode (BASELINE configs[4]'s arithmetic:
+    # half storage, half-operand contractions), timed after and apart from the fp32 region above
+    fp16_leg = None
+    if world == 1 and not args.fp16 and not args.no_fp16_leg:
+        del wl, step
+        wl16 = build_workload(True)
+        for _ in range(max(args.warmup // 2, 3)):
+            wl16['step']()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            wl16['step']()
+        fence()
+        e16 = time.perf_counter() - t1
+        fp16_leg = {"value": round(B * args.steps / e16, 3), "unit": "imgs/s", "ms_per_step": round(e16 / args.steps * 1e3, 3),
+                    "vs_fp32_line": round(elapsed / e16, 4),
+                    "dtype": "f16 storage (pyramid, RoI features, parameters), f16 MFMA products, fp32 accumulate",
+                    "note": "wrap_fp16_model on the same modules and inputs; not the headline value"}
+        del wl16
 
     if rank == 0:
         imgs = world * B * args.steps
@@ -348,6 +377,8 @@ def main():
             "stage_ms_per_step": {"arfpn_hbm_stages": round(fpn_ms, 4), "nonlocal_fwd_bwd": round(nl_ms, 4),
                                   "conv3x3_fwd_and_dgrad": round(sum(conv_ms) / args.steps, 4)},
         }
+        if fp16_leg is not None:
+            out["fp16_mode"] = fp16_leg
         if world == 1 and not args.no_cpu_baseline and not args.fp16:
             # (outside the timed region) the CPU leg doubles as the checker of this very workload
             def device_run(P):

@@ -36,7 +36,8 @@ def _rel_l2(a, b):
 def decisions_from_tap(tap, refine_level=2):
     """arfe_amd.functional's decision tap (the tensors the device forward saved for its own backward) -> Decisions on the CPU."""
     am = tap.get('argmax')
-    return O.Decisions(argmax=[am[i].cpu().long() for i in range(refine_level)] if am is not None else None,
+    return O.Decisions(argmax=[am[i].cpu().long() for i in range(refine_level)] if (am is not None and refine_level > 0) else
+                       ([] if refine_level == 0 else None),
                        gate_a=[t.cpu() > 0 for t in tap['gate_a']], gate_b=[t.cpu() > 0 for t in tap['gate_b']],
                        **{k: tap[k].cpu() > 0 for k in ('lw', 'lh', 'z2', 'f1', 'f2')})
 

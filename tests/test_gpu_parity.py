@@ -1215,10 +1215,9 @@ def test_fp16_mode_dtype_mismatch_raises_like_the_reference(dev):
 def test_shape_sweep_in_exact_fp32_mode():
     """tools/fuzz_shapes.py: the whole path (neck -> 3-RoI extractor -> head, fwd+bwd) on five unusual configurations
     (C = 20 / 36 / 128 / 8 / 320, B = 1..3, R = 1..200, every refine level, odd map sizes) against the oracle, run with
-    ARFE_GEMM_F32=1 in a fresh process: with exact-fp32 contractions the indexing of every kernel shows at ~1e-6, and only
-    an occasional ReLU kink (pre-activation within rounding of zero, ~1 per million conv outputs) is left, which the
-    script's L2 criterion (2e-3) tolerates.  In the default bf16x3 mode the same sweep measures <= 4e-3 L2 on the conv
-    bias gradients of the two widest cases, all of it such flips (they vanish here)."""
+    ARFE_GEMM_F32=1 in a fresh process: with exact-fp32 contractions the indexing of every kernel shows at ~1e-6.  The
+    script counts the ReLU / argmax choices that differ from the oracle's and bounds every gradient in max-norm (1e-3)
+    against the oracle evaluated under the device's choices (oracle/parity.py)."""
     import os
     import subprocess
     import sys
@@ -1233,13 +1232,13 @@ def test_shape_sweep_in_exact_fp32_mode():
 def test_shape_sweep_in_default_bf16x3_mode():
     """The same sweep through the kernels that SHIP (bf16x3 contractions, generic tiles for these channel counts and
     RoI counts that are not multiples of 32): their tails and indexing are exercised here, not only by the exact-fp32
-    run above.  Bound 5e-3 L2 (measured <= 4e-3, conv bias gradients of the two widest cases: ReLU-kink flips)."""
+    run above.  Same criterion: forward 1e-4, gradients 1e-3 in max-norm under the device's choices, flipped choices counted."""
     import os
     import subprocess
     import sys
     from conftest import ROOT
     env = {k: v for k, v in os.environ.items() if k not in ('ARFE_GEMM_F32', 'ARFE_CONV_STAGE_ONCE', 'ARFE_GEMM_PLAN')}
-    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'fuzz_shapes.py'), '--l2', '5e-3'], env=env, cwd=ROOT,
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'fuzz_shapes.py')], env=env, cwd=ROOT,
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert out.stdout.count('case ') == 5
