@@ -354,15 +354,23 @@ __global__ __launch_bounds__(256) void roi_key_kernel(RoiLevels L, RoiSets S, in
 
 // order[rank] = id, rank = number of RoIs with a smaller (key, id): a counting rank is enough for a few thousand RoIs.
 // One wave per RoI, the lanes share the comparisons (a thread-per-RoI loop kept 12 CUs busy for 80 us at 3072 RoIs).
-__global__ __launch_bounds__(256) void roi_rank_kernel(int n, const uint32_t* __restrict__ keys, int32_t* __restrict__ order) {
+// Round 3: the order is GROUP-major - all RoIs of one set first, in spatial order, then the next set - so that a caller can
+// launch the sets one after the other (arfe_roialign_fwd_group) and start a consumer of one set's slice while the next set is
+// still being extracted.  Processing group g holds set (g + 1) % nsets: with the AR-RFF sets (ori, w, h) the two enlarged-RoI
+// sets, which feed the gating convs, come first and the original RoIs, needed only at the fusion, last.
+__device__ __forceinline__ int roi_group_of_set(int s, int nsets) { return s == 0 ? nsets - 1 : s - 1; }
+__global__ __launch_bounds__(256) void roi_rank_kernel(int n, const uint32_t* __restrict__ keys, int32_t* __restrict__ order,
+                                                       int R, int nsets) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= n) return;
     const uint32_t mine = keys[i];
+    const int gi = roi_group_of_set(i / R, nsets);
     int cnt = 0;
     for (int j = lane; j < n; j += 64) {
         const uint32_t o = keys[j];
-        cnt += (o < mine || (o == mine && j < i)) ? 1 : 0;
+        const int gj = roi_group_of_set(j / R, nsets);
+        cnt += (gj < gi || (gj == gi && (o < mine || (o == mine && j < i)))) ? 1 : 0;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
@@ -378,7 +386,7 @@ template <class FT, class OT>
 __global__ __launch_bounds__(256) void roialign_fwd_sep_kernel(RoiLevels L, RoiSets S, int P, int sample_num,
                                                                const RoiWeightHdr* __restrict__ hdr,
                                                                const float* __restrict__ wtab, int nslices,
-                                                               OT* __restrict__ out, int64_t out_roi_stride) {
+                                                               OT* __restrict__ out, int64_t out_roi_stride, int slot0) {
     __shared__ __attribute__((aligned(16))) float wyT_s[RW_EXT][8];   // [window row][bin], pre-scaled by 1/samples
     __shared__ float wx_s[7][RW_EXT];
     __shared__ float U_s[4][7][64];                                    // one 64-column chunk of a wave's row sums
@@ -387,7 +395,7 @@ __global__ __launch_bounds__(256) void roialign_fwd_sep_kernel(RoiLevels L, RoiS
     // with 8 slices an XCD only ever sees its own 32 channels of the pyramid, and the RoIs come in spatial order.
     // Slot r of the header / weight tables was written for the r-th RoI of that order, so everything this workgroup
     // needs hangs off blockIdx alone (one global round trip before the window reads, not a chain of four).
-    const int slot = blockIdx.x / nslices;
+    const int slot = slot0 + blockIdx.x / nslices;
     const RoiWeightHdr* hp = hdr + slot;
     const int id = hp->id;
     const int s = id / S.R, k = id - s * S.R;
@@ -851,49 +859,105 @@ extern "C" int64_t arfe_roialign_fwd_workspace_bytes(int32_t nsets, int32_t R) {
     return (int64_t)nsets * R * ((int64_t)sizeof(RoiWeightHdr) + (int64_t)2 * 7 * RW_EXT * sizeof(float) + 8) + 64;
 }
 
-static int32_t roialign_fwd_any(const arfe_pyramid_t* pyr, const void* const* feats_any, const int32_t* strides,
-                                int32_t nsets, int32_t R, const float* const* rois, const int64_t* const* levels,
-                                int32_t pooled, int32_t sample_num, void* out, int64_t out_roi_stride,
-                                void* workspace, void* stream, bool half_io) {
-    const float* const* feats = (const float* const*)feats_any;      // (addresses only: the kernel instantiation knows the type)
+namespace {
+struct RoiFwdPlan {
+    RoiLevels L; RoiSets S;
+    int nroi, nslices;
+    RoiWeightHdr* hdr; float* wtab; uint32_t* keys; int32_t* order;
+};
+int32_t roialign_fwd_plan(RoiFwdPlan& p, const arfe_pyramid_t* pyr, const void* const* feats_any, const int32_t* strides,
+                          int32_t nsets, int32_t R, const float* const* rois, const int64_t* const* levels, int32_t pooled,
+                          int32_t sample_num, void* workspace) {
     int32_t rc = check_pyramid(pyr);
     if (rc) return rc;
     ARFE_CHECK_ARG(R >= 0 && nsets >= 1 && nsets <= RB_MAXSETS && sample_num >= 0, ARFE_ERR_ARG, "roialign_fwd: bad arguments");
     ARFE_CHECK_ARG(pooled == 7, ARFE_ERR_ARG, "roialign_fwd: only 7x7 pooling has a kernel (got %d)", pooled);
     if (R == 0) return ARFE_OK;
-    ARFE_CHECK_ARG(feats && strides && rois && levels && out && workspace, ARFE_ERR_ARG, "roialign_fwd: null pointer");
-    RoiLevels L;
-    ARFE_CHECK_ARG(fill_roi_levels(L, pyr, feats, nullptr, strides) == ARFE_OK, ARFE_ERR_ARG, "roialign_fwd: bad level table");
-    RoiSets S;
-    S.nsets = nsets; S.R = R;
-    for (int i = 0; i < RB_MAXSETS; ++i) { S.rois[i] = nullptr; S.levels[i] = nullptr; }
+    ARFE_CHECK_ARG(strides && rois && levels && workspace, ARFE_ERR_ARG, "roialign_fwd: null pointer");
+    ARFE_CHECK_ARG(fill_roi_levels(p.L, pyr, (const float* const*)feats_any, nullptr, strides) == ARFE_OK, ARFE_ERR_ARG,
+                   "roialign_fwd: bad level table");
+    p.S.nsets = nsets; p.S.R = R;
+    for (int i = 0; i < RB_MAXSETS; ++i) { p.S.rois[i] = nullptr; p.S.levels[i] = nullptr; }
     for (int i = 0; i < nsets; ++i) {
         ARFE_CHECK_ARG(rois[i] && levels[i], ARFE_ERR_ARG, "roialign_fwd: null RoI set %d", i);
-        S.rois[i] = rois[i]; S.levels[i] = levels[i];
+        p.S.rois[i] = rois[i]; p.S.levels[i] = levels[i];
     }
-    const int nroi = nsets * R;
-    RoiWeightHdr* hdr = (RoiWeightHdr*)workspace;
-    float* wtab = (float*)(hdr + nroi);
-    hipStream_t st = as_stream(stream);
-    uint32_t* keys = (uint32_t*)(wtab + (int64_t)nroi * 2 * 7 * RW_EXT);
-    int32_t* order = (int32_t*)(keys + nroi);
-    const int nslices = cdiv(L.C, RF_CH);
-    ARFE_CHECK_ARG((int64_t)nroi * nslices < (int64_t)1 << 31, ARFE_ERR_ARG, "roialign_fwd: too many RoIs");
-    hipLaunchKernelGGL(roi_key_kernel, dim3(cdiv(nroi, 256)), dim3(256), 0, st, L, S, nroi, pooled, sample_num, keys);
+    p.nroi = nsets * R;
+    p.hdr = (RoiWeightHdr*)workspace;
+    p.wtab = (float*)(p.hdr + p.nroi);
+    p.keys = (uint32_t*)(p.wtab + (int64_t)p.nroi * 2 * 7 * RW_EXT);
+    p.order = (int32_t*)(p.keys + p.nroi);
+    p.nslices = cdiv(p.L.C, RF_CH);
+    ARFE_CHECK_ARG((int64_t)p.nroi * p.nslices < (int64_t)1 << 31, ARFE_ERR_ARG, "roialign_fwd: too many RoIs");
+    return ARFE_OK;
+}
+// the RoI-only half: processing order (group-major, spatial inside a group) and the per-RoI weight tables
+int32_t roialign_fwd_prep(const RoiFwdPlan& p, int pooled, int sample_num, hipStream_t st) {
+    hipLaunchKernelGGL(roi_key_kernel, dim3(cdiv(p.nroi, 256)), dim3(256), 0, st, p.L, p.S, p.nroi, pooled, sample_num, p.keys);
     ARFE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(roi_rank_kernel, dim3(cdiv(nroi, 4)), dim3(256), 0, st, nroi, (const uint32_t*)keys, order);
+    hipLaunchKernelGGL(roi_rank_kernel, dim3(cdiv(p.nroi, 4)), dim3(256), 0, st, p.nroi, (const uint32_t*)p.keys, p.order, p.S.R,
+                       p.S.nsets);
     ARFE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(roi_weight_table_kernel, dim3(nroi), dim3(256), 0, st, L, S, pooled, sample_num, hdr, wtab,
-                       (const int32_t*)order, 0);
-    ARFE_CHECK_LAUNCH();
-    if (half_io)
-        hipLaunchKernelGGL((roialign_fwd_sep_kernel<_Float16, _Float16>), dim3(nroi * nslices), dim3(256), 0, st, L, S, pooled,
-                           sample_num, (const RoiWeightHdr*)hdr, (const float*)wtab, nslices, (_Float16*)out, out_roi_stride);
-    else
-        hipLaunchKernelGGL((roialign_fwd_sep_kernel<float, float>), dim3(nroi * nslices), dim3(256), 0, st, L, S, pooled,
-                           sample_num, (const RoiWeightHdr*)hdr, (const float*)wtab, nslices, (float*)out, out_roi_stride);
+    hipLaunchKernelGGL(roi_weight_table_kernel, dim3(p.nroi), dim3(256), 0, st, p.L, p.S, pooled, sample_num, p.hdr, p.wtab,
+                       (const int32_t*)p.order, 0);
     ARFE_CHECK_LAUNCH();
     return ARFE_OK;
+}
+// the extraction of processing groups [g0, g0 + gcount)
+int32_t roialign_fwd_run(const RoiFwdPlan& p, int pooled, int sample_num, void* out, int64_t out_roi_stride, int g0, int gcount,
+                         bool half_io, hipStream_t st) {
+    const int slot0 = g0 * p.S.R, nslot = gcount * p.S.R;
+    if (nslot <= 0) return ARFE_OK;
+    if (half_io)
+        hipLaunchKernelGGL((roialign_fwd_sep_kernel<_Float16, _Float16>), dim3(nslot * p.nslices), dim3(256), 0, st, p.L, p.S,
+                           pooled, sample_num, (const RoiWeightHdr*)p.hdr, (const float*)p.wtab, p.nslices, (_Float16*)out,
+                           out_roi_stride, slot0);
+    else
+        hipLaunchKernelGGL((roialign_fwd_sep_kernel<float, float>), dim3(nslot * p.nslices), dim3(256), 0, st, p.L, p.S, pooled,
+                           sample_num, (const RoiWeightHdr*)p.hdr, (const float*)p.wtab, p.nslices, (float*)out, out_roi_stride,
+                           slot0);
+    ARFE_CHECK_LAUNCH();
+    return ARFE_OK;
+}
+}  // namespace
+
+static int32_t roialign_fwd_any(const arfe_pyramid_t* pyr, const void* const* feats_any, const int32_t* strides,
+                                int32_t nsets, int32_t R, const float* const* rois, const int64_t* const* levels,
+                                int32_t pooled, int32_t sample_num, void* out, int64_t out_roi_stride,
+                                void* workspace, void* stream, bool half_io) {
+    RoiFwdPlan p;
+    int32_t rc = roialign_fwd_plan(p, pyr, feats_any, strides, nsets, R, rois, levels, pooled, sample_num, workspace);
+    if (rc || R == 0) return rc;
+    ARFE_CHECK_ARG(feats_any && out, ARFE_ERR_ARG, "roialign_fwd: null pointer");
+    rc = roialign_fwd_prep(p, pooled, sample_num, as_stream(stream));
+    if (rc) return rc;
+    return roialign_fwd_run(p, pooled, sample_num, out, out_roi_stride, 0, nsets, half_io, as_stream(stream));
+}
+
+// The forward in two parts (round 3).  _prepare is the RoI-only part (processing order, weight tables): it needs no feature
+// map.  _group extracts the RoIs of processing groups [group_first, group_first + group_count) - group g is RoI set
+// (g + 1) % nsets, see roi_rank_kernel - on a prepared workspace: a caller launches the sets one after the other and starts the
+// consumer of a set's channel slice (the AR-RFF gating convs) while the next set is extracted.  arfe_roialign_fwd = both.
+extern "C" int32_t arfe_roialign_fwd_prepare(const arfe_pyramid_t* pyr, const int32_t* strides, int32_t nsets, int32_t R,
+                                             const float* const* rois, const int64_t* const* levels, int32_t pooled,
+                                             int32_t sample_num, void* workspace, void* stream) {
+    RoiFwdPlan p;
+    int32_t rc = roialign_fwd_plan(p, pyr, nullptr, strides, nsets, R, rois, levels, pooled, sample_num, workspace);
+    if (rc || R == 0) return rc;
+    return roialign_fwd_prep(p, pooled, sample_num, as_stream(stream));
+}
+extern "C" int32_t arfe_roialign_fwd_group(const arfe_pyramid_t* pyr, const float* const* feats, const int32_t* strides,
+                                           int32_t nsets, int32_t R, const float* const* rois, const int64_t* const* levels,
+                                           int32_t pooled, int32_t sample_num, float* out, int64_t out_roi_stride,
+                                           const void* workspace, int32_t group_first, int32_t group_count, void* stream) {
+    RoiFwdPlan p;
+    int32_t rc = roialign_fwd_plan(p, pyr, (const void* const*)feats, strides, nsets, R, rois, levels, pooled, sample_num,
+                                   const_cast<void*>(workspace));
+    if (rc || R == 0) return rc;
+    ARFE_CHECK_ARG(feats && out, ARFE_ERR_ARG, "roialign_fwd_group: null pointer");
+    ARFE_CHECK_ARG(group_first >= 0 && group_count >= 0 && group_first + group_count <= nsets, ARFE_ERR_ARG,
+                   "roialign_fwd_group: groups [%d, %d) outside [0, %d)", group_first, group_first + group_count, nsets);
+    return roialign_fwd_run(p, pooled, sample_num, out, out_roi_stride, group_first, group_count, false, as_stream(stream));
 }
 
 extern "C" int32_t arfe_roialign_fwd(const arfe_pyramid_t* pyr, const float* const* feats, const int32_t* strides,

@@ -436,6 +436,29 @@ def roialign_fwd_op(feats, strides, roi_sets, level_sets, out, pooled=7, sample_
                  ptr_array(level_sets), pooled, sample_num, ptr(out), out.stride(0), ptr(ws), stream()), "arfe_roialign_fwd")
 
 
+def roialign_fwd_prepare_op(feats, strides, roi_sets, level_sets, pooled=7, sample_num=0):
+    """RoI-only part of the forward (processing order, weight tables) -> workspace for roialign_fwd_group_op."""
+    pyr = Pyramid.of(feats, 0)
+    nsets, R = len(roi_sets), roi_sets[0].shape[0]
+    ws = _ws(hip.lib().arfe_roialign_fwd_workspace_bytes(nsets, R), feats[0].device)
+    check(hip.lib().arfe_roialign_fwd_prepare(ctypes.byref(pyr), _stride_array(strides), nsets, R, ptr_array(roi_sets),
+                                              ptr_array(level_sets), pooled, sample_num, ptr(ws), stream()),
+          "arfe_roialign_fwd_prepare")
+    return ws
+
+
+def roialign_fwd_group_op(feats, strides, roi_sets, level_sets, out, ws, group_first, group_count, pooled=7, sample_num=0):
+    """Extraction of processing groups [group_first, +group_count) (group g = RoI set (g + 1) % nsets) into `out`."""
+    hip.require_f32_cuda(*feats, *roi_sets, out)
+    pyr = Pyramid.of(feats, 0)
+    nsets, R = len(roi_sets), roi_sets[0].shape[0]
+    with probe('roialign_fwd'):
+        check(hip.lib().arfe_roialign_fwd_group(ctypes.byref(pyr), ptr_array(feats), _stride_array(strides), nsets, R,
+                                                ptr_array(roi_sets), ptr_array(level_sets), pooled, sample_num, ptr(out),
+                                                out.stride(0), ptr(ws), group_first, group_count, stream()),
+              "arfe_roialign_fwd_group")
+
+
 def roialign_bwd_prepare_op(feats, strides, roi_sets, level_sets, pooled=7, sample_num=0):
     """The RoI-only part of the backward (tile lists, weight tables) -> workspace tensor; launched on the CURRENT stream
     (RoIExtractFunction.forward puts it on the side stream, beside the forward RoIAlign)."""
@@ -674,9 +697,10 @@ def stack_predictors(wc, bc, wr, br):
     return torch.cat([wc, wr], 0), torch.cat([bc, br], 0)
 
 
-def _rff_head_forward(x, params, packs):
+def _rff_head_forward(x, params, packs, gate=None):
     """MultiBBoxHead.forward on contiguous fp32 tensors -> (cls, reg, saved tensors for _rff_head_backward).
-    packs: (pk_wh, pk_hh, pk_f) already ordered before the current stream, or None (packed here)."""
+    packs: (pk_wh, pk_hh, pk_f) already ordered before the current stream, or None (packed here).
+    gate: (lw, lh) when the caller has launched the two gating convs already (ordered before the current stream)."""
     w_wh, b_wh, w_hh, b_hh, w_f, b_f, w1, b1, w2, b2, wc, bc, wr, br = params
     R, C3 = x.shape[0], x.shape[1]
     C = C3 // 3
@@ -690,10 +714,13 @@ def _rff_head_forward(x, params, packs):
         pk_wh, pk_hh, pk_f = packs
     rs = C3 * 49
     base = x.data_ptr()
-    # the two gating convs are independent: two 224-workgroup launches side by side pack the 256 CUs
-    lh = on_side(x.device, lambda: conv3x3_fwd_op(base + 4 * 2 * C * 49, rs, R, C, pk_hh, b_hh, True))
-    lw = conv3x3_fwd_op(base + 4 * C * 49, rs, R, C, pk_wh, b_wh, True)
-    join_side(x.device)
+    if gate is not None:
+        lw, lh = gate
+    else:
+        # the two gating convs are independent: two 224-workgroup launches side by side pack the 256 CUs
+        lh = on_side(x.device, lambda: conv3x3_fwd_op(base + 4 * 2 * C * 49, rs, R, C, pk_hh, b_hh, True))
+        lw = conv3x3_fwd_op(base + 4 * C * 49, rs, R, C, pk_wh, b_wh, True)
+        join_side(x.device)
     z = torch.empty(R, C, 7, 7, device=x.device)
     check(hip.lib().arfe_rff_fuse_fwd(R, C, base, rs, ptr(lw), ptr(lh), ptr(z), stream()), "arfe_rff_fuse_fwd")
     z2 = conv3x3_fwd_op(z.data_ptr(), C * 49, R, C, pk_f, b_f, True)
@@ -856,9 +883,31 @@ class RFFExtractHeadFunction(torch.autograd.Function):
                     return ws, roialign_bwd_prezero_op(shapes, strides, roi_sets, ws)
                 prepared, ctx.dfeats = on_side(dev, prep)
                 ctx.prep_event = side_stream(dev).record_event()
+        gate = None
+        if R > 0 and os.environ.get('ARFE_ROI_PIPELINE', '0') == '1':
+            # Round 3 experiment, OFF by default (measured: no gain).  The three RoI sets are extracted one after the other
+            # (w, h, ori: arfe_roialign_fwd_group) on this stream and each gating conv starts on the side stream as soon as
+            # ITS set's channel slice is complete.  The extraction is vector-issue bound and so is the conv kernel's operand
+            # staging (the MFMAs share that issue port): side by side the two just time-slice the CUs - extraction of a set
+            # 100 -> 224 us, a gating conv 150 -> 270 us, 607 us from first extraction to last conv against 604 us in sequence.
+            main, side = torch.cuda.current_stream(), side_stream(dev)
+            ws_f = roialign_fwd_prepare_op(feats, strides, roi_sets, levels, pooled, sample_num)
+            rs, base = 3 * C * 49, x.data_ptr()
+            x.record_stream(side)
+            roialign_fwd_group_op(feats, strides, roi_sets, levels, x, ws_f, 0, 1, pooled, sample_num)       # set 1: w-RoIs
+            side.wait_event(main.record_event())
+            with torch.cuda.stream(side):
+                lw = conv3x3_fwd_op(base + 4 * C * 49, rs, R, C, packs[0], params[1], True)
+            roialign_fwd_group_op(feats, strides, roi_sets, levels, x, ws_f, 1, 1, pooled, sample_num)       # set 2: h-RoIs
+            side.wait_event(main.record_event())
+            with torch.cuda.stream(side):
+                lh = conv3x3_fwd_op(base + 4 * 2 * C * 49, rs, R, C, packs[1], params[3], True)
+            roialign_fwd_group_op(feats, strides, roi_sets, levels, x, ws_f, 2, 1, pooled, sample_num)       # set 0: the RoIs
+            gate = (lw, lh)
+        elif R > 0:
             roialign_fwd_op(feats, strides, roi_sets, levels, x, pooled, sample_num)
-        join_side(dev)                    # packs (and the prepare, long finished) before the first conv
-        cls, reg, saved = _rff_head_forward(x, params, packs)
+        join_side(dev)                    # packs, the gating convs (and the prepare, long finished) before the head goes on
+        cls, reg, saved = _rff_head_forward(x, params, packs, gate)
         ctx.cfg = (tuple(strides), pooled, sample_num, nfeat)
         ctx.shapes = [f.shape for f in feats]
         ctx.has_prepared = prepared is not None

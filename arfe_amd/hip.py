@@ -63,6 +63,8 @@ SIGNATURES = {
     "arfe_rff_roi_sets": (_i32, [_i32, _vp, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "arfe_roialign_fwd_workspace_bytes": (_i64, [_i32, _i32]),
     "arfe_roialign_fwd": (_i32, [_PP, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp]),
+    "arfe_roialign_fwd_prepare": (_i32, [_PP, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp]),
+    "arfe_roialign_fwd_group": (_i32, [_PP, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _i32, _i32, _vp]),
     "arfe_roialign_fwd_h": (_i32, [_PP, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp]),
     "arfe_roialign_bwd_prepared_h": (_i32, [_PP, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp]),
     "arfe_roialign_bwd_workspace_bytes": (_i64, [_PP, _i32, _i32]),

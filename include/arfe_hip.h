@@ -186,6 +186,19 @@ int32_t arfe_roialign_fwd(const arfe_pyramid_t* pyr, const float* const* feats, 
                           int32_t pooled, int32_t sample_num, float* out, int64_t out_roi_stride,
                           void* workspace, void* stream);
 
+/* The forward in two parts: _prepare is the RoI-only part (processing order, weight tables; needs no feature map, same
+ * workspace as arfe_roialign_fwd); _group extracts the RoIs of processing groups [group_first, group_first + group_count) on a
+ * prepared workspace.  Group g holds RoI set (g + 1) % nsets - for the AR-RFF sets (ori, w, h): w, h, ori - so a caller starts
+ * the gating conv of a set's channel slice while the next set is still being extracted.  arfe_roialign_fwd = _prepare + every
+ * group. */
+int32_t arfe_roialign_fwd_prepare(const arfe_pyramid_t* pyr, const int32_t* strides, int32_t nsets, int32_t R,
+                                  const float* const* rois, const int64_t* const* levels, int32_t pooled, int32_t sample_num,
+                                  void* workspace, void* stream);
+int32_t arfe_roialign_fwd_group(const arfe_pyramid_t* pyr, const float* const* feats, const int32_t* strides, int32_t nsets,
+                                int32_t R, const float* const* rois, const int64_t* const* levels, int32_t pooled,
+                                int32_t sample_num, float* out, int64_t out_roi_stride, const void* workspace,
+                                int32_t group_first, int32_t group_count, void* stream);
+
 /* The same forward with HALF feature maps and a HALF output (the extractor of a model in the reference's fp16 mode reads
  * the half maps a neck handed on and returns half RoI features, single_level.py:109 @force_fp32(out_fp16=True)): the kernel
  * converts on load / store, the arithmetic is the fp32 one - results equal a half -> float pass, arfe_roialign_fwd and a float ->

@@ -317,6 +317,27 @@ def test_roialign_bwd_prepared_route_equals_single_call(Fn, O, dev):
         assert torch.equal(Fn.roi_extract(feats, sets, O.STRIDES, levels=lv), ya)
 
 
+def test_roialign_forward_in_groups_equals_single_call(Fn, O, dev):
+    """arfe_roialign_fwd_prepare + arfe_roialign_fwd_group (one RoI set per launch, processing groups w, h, ori) fill the same
+    [R, 3C, 7, 7] concat as the single call, bit for bit; each group writes only its own channel slice."""
+    C = 8
+    g = torch.Generator().manual_seed(29)
+    feats = [torch.randn(2, C, h, w, generator=g).to(dev) for h, w in PYRAMIDS['mid']]
+    rois = O.synth_rois(2, 40, img_w=384, img_h=256, seed=6).to(dev)
+    h_r, w_r, lv = Fn.rff_roi_sets_op(rois, 5)
+    sets = [rois, w_r, h_r]
+    ref = torch.empty(rois.shape[0], 3 * C, 7, 7, device=dev)
+    Fn.roialign_fwd_op(feats, O.STRIDES, sets, lv, ref)
+    ws = Fn.roialign_fwd_prepare_op(feats, O.STRIDES, sets, lv)
+    out = torch.full_like(ref, float('nan'))
+    for grp, s in ((0, 1), (1, 2), (2, 0)):                 # group g holds RoI set (g + 1) % 3
+        Fn.roialign_fwd_group_op(feats, O.STRIDES, sets, lv, out, ws, grp, 1)
+        assert torch.equal(out[:, s * C:(s + 1) * C], ref[:, s * C:(s + 1) * C])
+        untouched = [t for t in range(3) if t not in [(k + 1) % 3 for k in range(grp + 1)]]
+        assert all(torch.isnan(out[:, t * C:(t + 1) * C]).all() for t in untouched)
+    assert torch.equal(out, ref)
+
+
 def test_roialign_golden(Fn, dev):
     d = load_golden('roialign.npz')
     feats = [d[f'feat{i}'].to(dev).requires_grad_(True) for i in range(5)]

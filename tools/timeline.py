@@ -13,7 +13,7 @@ for r in csv.DictReader(open(path)):
     rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), int(r['Queue_Id']), r['Kernel_Name']))
 rows.sort()
 # step boundaries: a gather kernel marks the neck forward of a new step
-starts = [i for i, r in enumerate(rows) if 'fpn_gather_fwd_kernel' in r[3]]
+starts = [i for i, r in enumerate(rows) if 'fpn_gather_fwd_kernel' in r[3] or 'fpn_gather_gate_kernel' in r[3]]
 bounds = []
 for s in starts:
     # the step begins at the first kernel after the previous step's end: walk back over kernels that belong to this
