@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libarfe_hip.so")
 SOURCES = ["api.hip", "fpn.hip", "fpn_stream.hip", "roi.hip", "gemm_ops.hip", "fpn_base.hip"]
-HEADERS = ["common.hpp", "gemm_f32.hpp", "gemm_bf16x3.hpp", "conv_stage_once.hpp", "conv_wgrad_stage_once.hpp", os.path.join("..", "..", "include", "arfe_hip.h")]
+HEADERS = ["common.hpp", "gemm_f32.hpp", "gemm_bf16x3.hpp", "conv_stage_once.hpp", "conv_wgrad_stage_once.hpp", os.path.join("..", "..", "include", "arfe_hip.h")]   # (fpn_stream.hip is in SOURCES: it is hashed with them)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]
 LDFLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc"]

@@ -51,6 +51,7 @@ def pmc_traffic(kernel_substr):
     (`_meta.csrc_sha` == arfe_amd.build.sources_sha()); otherwise traffic is null and the note says why."""
     import glob
     from arfe_amd.build import sources_sha
+    pmc_traffic.mfma = None
     paths = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_hbm_traffic.json')))
     if not paths:
         return None, "no committed PMC profile"
@@ -62,7 +63,8 @@ def pmc_traffic(kernel_substr):
         if meta.get("csrc_sha") != sources_sha():
             return None, f"{name} was measured on other kernel sources (csrc sha {meta.get('csrc_sha')}): not quoted"
         for k, v in d["kernels"].items():
-            if all(t in k for t in kernel_substr):
+            if all(t in k for t in kernel_substr) and 'EpiConv, 1' not in k:
+                pmc_traffic.mfma = v.get("mfma")
                 return v["hbm_bytes_per_launch"], f"bytes/launch, PMC passes in {name} (csrc sha {meta['csrc_sha']})"
     except Exception as e:      # a malformed profile must not take the bench line down
         return None, f"{name}: {type(e).__name__}"
@@ -365,6 +367,7 @@ def main():
                          "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(ach / peak, 4),
                          "traffic": traffic, "traffic_unit": traffic_note,
+                         "mfma_pmc": getattr(pmc_traffic, 'mfma', None),
                          "algorithmic_bytes_per_launch": int(2 * R * 256 * 49 * 4 + 9 * 256 * 256 * 4),
                          "mfma_flop_per_algorithmic_flop": 1 if f32_mode else 3,
                          "frac_of_exact_fp32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
