@@ -12,15 +12,25 @@
 // lane-linear per wave-instruction (16 rows x 4 octets), so the XOR swizzle of the rows (xs_swz) is applied to the SOURCE
 // octet each lane fetches.  The step's DMA is issued at the top of the iteration into the other buffer and has the whole
 // MFMA phase to land; the barrier that ends the iteration (vmcnt(0) + s_barrier) retires it.
+// Round 3: the tile's 224 pixels are 32 image rows of 7 (a tile starts on a row: 224 = 32*7), and a wave's 16-column MFMA block j
+// is now pixel COLUMN j of its 16 rows (lane = row) instead of 16 consecutive pixels.  A tap that looks left (right) finds
+// column 0 (6) outside every map: that whole block is skipped - 6 of 9 taps skip 1 of 7 blocks, 9.5 % of the MFMAs.  The
+// row validity (taps that look up / down) is one address select per lane and tap; the seven blocks of a tap are immediate
+// offsets from it.  In the epilogue a lane holds the 7 consecutive outputs of an image row per output channel: 28-byte
+// stores, 16 lanes = 16 consecutive rows.
 #pragma once
 #include "gemm_bf16x3.hpp"
 
 namespace arfe {
 
 constexpr int CS_BN = 224, CS_HALO = 8, CS_ROWS = CS_BN + 2 * CS_HALO;      // 240 staged pixel rows, row 240 = zeros
-constexpr int CS_BLD = 40;                                                  // B image: 80-byte rows (shifted reads: no swizzle)
+#ifndef ARFE_CS_BLD
+#define ARFE_CS_BLD 40
+#endif
+constexpr int CS_BLD = ARFE_CS_BLD;                                         // B image: 80-byte rows (shifted reads: no swizzle)
+constexpr int CS_ZROWS = 7;                                                 // zero rows behind the image: one per column block
 constexpr int CS_A_IMG = XL_BM * XS_LD;                                     // A image (swizzled 64-byte rows), elements
-constexpr int CS_B_IMG = (CS_ROWS + 1) * CS_BLD;
+constexpr int CS_B_IMG = (CS_ROWS + CS_ZROWS) * CS_BLD;
 constexpr int CS_LDS_BYTES = (2 * 2 * CS_A_IMG + 2 * 2 * CS_B_IMG) * 2;     // 2 buffers x (hi, lo) of each operand
 
 struct ConvStageDims { int M, N, C, tiles_n, dbg; };   // dbg: probe switches (ARFE_CONV_DBG), 0 in production
@@ -46,7 +56,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stage_once_kernel(ConvStageDim
         for (int j = 0; j < 7; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // zero rows of the four B images
-    for (int i = tid; i < 4 * CS_BLD; i += 512) (cs_lds + 4 * CS_A_IMG + (i / CS_BLD) * CS_B_IMG + CS_ROWS * CS_BLD)[i % CS_BLD] = 0;
+    for (int i = tid; i < 4 * CS_ZROWS * CS_BLD; i += 512)
+        (cs_lds + 4 * CS_A_IMG + (i / (CS_ZROWS * CS_BLD)) * CS_B_IMG + CS_ROWS * CS_BLD)[i % (CS_ZROWS * CS_BLD)] = 0;
 
     // ---- A staging by LDS-DMA: a wave-instruction fills 64 consecutive 16-byte chunks of an image = 16 rows x 4 octets;
     // wave w takes chunks [(2*i + ...)]: instruction i of wave w covers chunks (i*8 + w)*64 .. +63.  LDS chunk (row, pos)
@@ -105,28 +116,23 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stage_once_kernel(ConvStageDim
             }
         }
     };
-    // ---- per-lane fragment geometry: column block j of this wave covers tile pixels wn*112 + j*16 + l15 ----
-    int b_base[7];          // element offset of the UNSHIFTED source row (tile pixel + halo) + this lane's k-octet
-    unsigned vm[7];         // bit t: tap t reads inside the 7x7 map
-#pragma unroll
-    for (int j = 0; j < 7; ++j) {
-        const int nl = wn * 112 + j * 16 + l15;
-        b_base[j] = (nl + CS_HALO) * CS_BLD + 8 * lq;
-        int g = n0 + nl;
-        g = g < d.N ? g : d.N - 1;
-        const int p = g % 49, py = p / 7, px = p - py * 7;
-        unsigned m = 0;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
-            m |= ((unsigned)yy < 7u && (unsigned)xx < 7u) ? (1u << t) : 0u;
-        }
-        vm[j] = m;
-    }
+    // ---- per-lane fragment geometry: this wave owns image rows wn*16 .. +15 of the tile, lane l15 = row, block j = column ----
+    const int row_n = n0 + wn * 112 + l15 * 7;                                // first pixel of this lane's image row
+    const int b_base = (wn * 112 + l15 * 7 + CS_HALO) * CS_BLD + 8 * lq;      // column 0, unshifted; column j: + j*CS_BLD
     const int zero_off = CS_ROWS * CS_BLD + 8 * lq;
+    int b_off[3];           // per dy: the row to read from (the zero rows when the source row is outside the 7x7 map)
+    {
+        const int g = row_n < d.N ? row_n : d.N - 7;
+        const int py = (g / 7) % 7;
+        b_off[0] = py > 0 ? b_base - 7 * CS_BLD : zero_off;
+        b_off[1] = b_base;
+        b_off[2] = py < 6 ? b_base + 7 * CS_BLD : zero_off;
+    }
     const int frag_oct = 8 * (lq ^ xs_swz(l15));
-    auto mma = [&](int abuf, int bbuf, int tap) {
-        const int sh = ((tap / 3 - 1) * 7 + (tap % 3 - 1)) * CS_BLD;        // wave-uniform row shift, in elements
+    // dxc = 0 / 1 / 2: the tap looks left / straight / right; block 0 (6) is not computed when it looks left (right): its
+    // source column is outside every map.  One code path: the two conditional blocks are wave-uniform branches.
+    auto mma = [&](int abuf, int bbuf, int dy, int dxc) {
+        const int boff = b_off[dy + 1] + (dxc - 1) * CS_BLD;
         bf16x8 ah[4], al[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -137,20 +143,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stage_once_kernel(ConvStageDim
         }
         bf16x8 bh[2], bl[2];
         {
-            const int off = ((vm[0] >> tap) & 1u) ? b_base[0] + sh : zero_off;
-            bh[0] = *reinterpret_cast<const bf16x8*>(img_b(bbuf, 0) + off);
-            if constexpr (PREC == 0) bl[0] = *reinterpret_cast<const bf16x8*>(img_b(bbuf, 1) + off);
+            bh[0] = *reinterpret_cast<const bf16x8*>(img_b(bbuf, 0) + boff);
+            if constexpr (PREC == 0) bl[0] = *reinterpret_cast<const bf16x8*>(img_b(bbuf, 1) + boff);
             else bl[0] = bh[0];
         }
 #pragma unroll
         for (int j = 0; j < 7; ++j) {
             if (j + 1 < 7) {
-                const int off = ((vm[j + 1] >> tap) & 1u) ? b_base[j + 1] + sh : zero_off;
-                bh[(j + 1) & 1] = *reinterpret_cast<const bf16x8*>(img_b(bbuf, 0) + off);
-                if constexpr (PREC == 0) bl[(j + 1) & 1] = *reinterpret_cast<const bf16x8*>(img_b(bbuf, 1) + off);
+                bh[(j + 1) & 1] = *reinterpret_cast<const bf16x8*>(img_b(bbuf, 0) + boff + (j + 1) * CS_BLD);
+                if constexpr (PREC == 0) bl[(j + 1) & 1] = *reinterpret_cast<const bf16x8*>(img_b(bbuf, 1) + boff + (j + 1) * CS_BLD);
                 else bl[(j + 1) & 1] = bh[(j + 1) & 1];
             }
             __builtin_amdgcn_sched_barrier(0);
+            if ((j == 0 && dxc == 0) || (j == 6 && dxc == 2)) continue;
             if constexpr (PREC == 1) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -182,13 +187,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stage_once_kernel(ConvStageDim
         if (s + 1 < nsteps && !(d.dbg & 8)) dma_a(s + 1, abuf ^ 1);     // the other buffer: its readers passed the last barrier
         if (next_b && slice + 2 < nslices && !(d.dbg & 4)) fetch_b(slice + 2);
         __builtin_amdgcn_sched_barrier(0);
-        if (!(d.dbg & 2)) mma(abuf, slice & 1, tap);
+        if (!(d.dbg & 2)) {
+            const int dy = tap / 3 - 1;
+            mma(abuf, slice & 1, dy, tap - (tap / 3) * 3);
+        }
         __syncthreads();                                // retires the DMA (vmcnt(0)) and frees buffer abuf
         abuf ^= 1;
     }
 
     if (d.dbg & 1) { if (acc[0][0][0] == 123.456f) epi.store_rb(0, 0, 0, acc[1][1][1], true, 0.f); return; }
-    // ---- epilogue: D layout lane -> column l15, rows 4*lq + r (as the 256x224 kernel) ----
+    // ---- epilogue: D layout lane -> image row l15 (all 7 columns: one per block), output channels 4*lq + r ----
     float rbias[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -197,17 +205,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stage_once_kernel(ConvStageDim
             const int m = m0 + wm * 64 + i * 16 + 4 * lq + r;
             rbias[i][r] = epi.row_bias(m < d.M ? m : d.M - 1);
         }
+    if (row_n >= d.N) return;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 7; ++j) {
-            const int n = n0 + wn * 112 + j * 16 + l15;
-            if (n >= d.N) continue;
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wm * 64 + i * 16 + 4 * lq + r;
+            if (m >= d.M) continue;
+            float v[7];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wm * 64 + i * 16 + 4 * lq + r;
-                if (m < d.M) epi.store_rb(0, m, n, acc[i][j][r], true, rbias[i][r]);
-            }
+            for (int j = 0; j < 7; ++j) v[j] = acc[i][j][r];
+            epi.store_row7(m, row_n, v, rbias[i][r]);
         }
 }
 

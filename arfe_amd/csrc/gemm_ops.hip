@@ -76,6 +76,33 @@ struct EpiConv {       // y[r*roi_stride + co*49 + p] = act(v + bias[co]) * [mas
         if (mask && !(epi_ld(mask, (int64_t)r * mask_roi_stride + m * 49 + p) > 0.f)) v = 0.f;
         y[(int64_t)r * roi_stride + m * 49 + p] = v;
     }
+    // one image row: the 7 consecutive pixels n .. n+6 (n a multiple of 7) of output channel m
+    __device__ __forceinline__ void store_row7(int m, int n, float (&v)[7], float b) const {
+        typedef float __attribute__((ext_vector_type(4), aligned(4))) f4u;
+        typedef float __attribute__((ext_vector_type(2), aligned(4))) f2u;
+        const int r = n / 49, p = n - r * 49;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            v[j] += b;
+            if (relu) v[j] = fmaxf(v[j], 0.f);
+        }
+        if (mask) {
+            // read-only operand: constant address space, so the loads may move ahead of earlier stores (see epi_ld)
+            typedef const f4u __attribute__((address_space(4)))* c4;
+            typedef const f2u __attribute__((address_space(4)))* c2;
+            const float* q = mask + (int64_t)r * mask_roi_stride + m * 49 + p;
+            const f4u m0 = *(c4)(uintptr_t)q;
+            const f2u m1 = *(c2)(uintptr_t)(q + 4);
+            const float m2 = epi_ld(q, 6);
+            v[0] = m0[0] > 0.f ? v[0] : 0.f; v[1] = m0[1] > 0.f ? v[1] : 0.f; v[2] = m0[2] > 0.f ? v[2] : 0.f;
+            v[3] = m0[3] > 0.f ? v[3] : 0.f; v[4] = m1[0] > 0.f ? v[4] : 0.f; v[5] = m1[1] > 0.f ? v[5] : 0.f;
+            v[6] = m2 > 0.f ? v[6] : 0.f;
+        }
+        float* o = y + (int64_t)r * roi_stride + m * 49 + p;
+        *reinterpret_cast<f4u*>(o) = f4u{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f2u*>(o + 4) = f2u{v[4], v[5]};
+        o[6] = v[6];
+    }
 };
 template <> struct epi_has_rowbias<EpiConv> { static constexpr bool value = true; };
 }  // namespace arfe
