@@ -20,6 +20,7 @@
 // stores, 16 lanes = 16 consecutive rows.
 #pragma once
 #include "gemm_bf16x3.hpp"
+#include <type_traits>
 
 namespace arfe {
 
@@ -131,69 +132,104 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stage_once_kernel(ConvStageDim
     const int frag_oct = 8 * (lq ^ xs_swz(l15));
     // dxc = 0 / 1 / 2: the tap looks left / straight / right; block 0 (6) is not computed when it looks left (right): its
     // source column is outside every map.  One code path: the two conditional blocks are wave-uniform branches.
-    auto mma = [&](int abuf, int bbuf, int dy, int dxc) {
-        const int boff = b_off[dy + 1] + (dxc - 1) * CS_BLD;
-        bf16x8 ah[4], al[4];
+    //
+    // Pipeline (round 3).  A step is one tap of one 32-channel slice: ONE MFMA K-step per (row block, column block), so a
+    // barrier per step with the fragment reads behind it left the matrix pipe idle while every wave of the workgroup waited
+    // for its first LDS reads (SQ_VALU_MFMA_BUSY = 50 % of the SIMD cycles).  Now the barrier sits in the MIDDLE of the step:
+    //   blocks 0..3 of step s | vmcnt(0) + barrier | DMA of step s+2, A fragments of step s+1 -> second register set,
+    //   blocks 4..6 of step s, first B fragment of step s+1 | blocks 0..3 of step s+1 | ...
+    // so the reads that follow the barrier have three blocks of MFMAs to land behind.  Buffer s&1 is free at the barrier of
+    // step s (its fragments were read before the barrier of step s-1 ... by every wave that reaches this one), and the DMA
+    // of step s+1 went out a whole step ago.  Steps are unrolled in pairs (the two register sets swap roles).
+    bf16x8 afh[2][4], afl[2][4];        // A fragments: [set][row block]
+    bf16x8 bh[2], bl[2];                // B fragments: slot = (global block index) & 1
+    auto boff_of = [&](int s) {
+        const int tap = s % 9;
+        const int dy = tap / 3, dxc = tap - dy * 3;
+        return b_off[dy] + (dxc - 1) * CS_BLD;
+    };
+    auto load_a = [&](int abuf, auto set_tag) {
+        constexpr int S = decltype(set_tag)::value;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int off = (wm * 64 + t * 16 + l15) * XS_LD + frag_oct;
-            ah[t] = *reinterpret_cast<const bf16x8*>(img_a(abuf, 0) + off);
-            if constexpr (PREC == 0) al[t] = *reinterpret_cast<const bf16x8*>(img_a(abuf, 1) + off);
-            else al[t] = ah[t];
-        }
-        bf16x8 bh[2], bl[2];
-        {
-            bh[0] = *reinterpret_cast<const bf16x8*>(img_b(bbuf, 0) + boff);
-            if constexpr (PREC == 0) bl[0] = *reinterpret_cast<const bf16x8*>(img_b(bbuf, 1) + boff);
-            else bl[0] = bh[0];
-        }
-#pragma unroll
-        for (int j = 0; j < 7; ++j) {
-            if (j + 1 < 7) {
-                bh[(j + 1) & 1] = *reinterpret_cast<const bf16x8*>(img_b(bbuf, 0) + boff + (j + 1) * CS_BLD);
-                if constexpr (PREC == 0) bl[(j + 1) & 1] = *reinterpret_cast<const bf16x8*>(img_b(bbuf, 1) + boff + (j + 1) * CS_BLD);
-                else bl[(j + 1) & 1] = bh[(j + 1) & 1];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if ((j == 0 && dxc == 0) || (j == 6 && dxc == 2)) continue;
-            if constexpr (PREC == 1) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah[i]), __builtin_bit_cast(f16x8, bh[j & 1]), acc[i][j], 0, 0, 0);
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j & 1], acc[i][j], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j & 1], acc[i][j], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j & 1], acc[i][j], 0, 0, 0);
-            }
+            afh[S][t] = *reinterpret_cast<const bf16x8*>(img_a(abuf, 0) + off);
+            if constexpr (PREC == 0) afl[S][t] = *reinterpret_cast<const bf16x8*>(img_a(abuf, 1) + off);
         }
     };
+    auto load_b = [&](int bbuf, int off, auto slot_tag) {
+        constexpr int S = decltype(slot_tag)::value;
+        bh[S] = *reinterpret_cast<const bf16x8*>(img_b(bbuf, 0) + off);
+        if constexpr (PREC == 0) bl[S] = *reinterpret_cast<const bf16x8*>(img_b(bbuf, 1) + off);
+    };
+    auto block = [&](auto j_tag, auto set_tag, auto slot_tag) {
+        constexpr int j = decltype(j_tag)::value, A = decltype(set_tag)::value, S = decltype(slot_tag)::value;
+        if constexpr (PREC == 1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, afh[A][i]), __builtin_bit_cast(f16x8, bh[S]), acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afl[A][i], bh[S], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afh[A][i], bl[S], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afh[A][i], bh[S], acc[i][j], 0, 0, 0);
+        }
+    };
+    // one step; P = s & 1: register set of its A fragments, and the parity of its first B slot (7 blocks per step)
+    auto step = [&](int s, auto p_tag) {
+        constexpr int P = decltype(p_tag)::value;
+        const int tap = s % 9, slice = s / 9;
+        const int dxc = tap - (tap / 3) * 3;
+        const int bbuf = slice & 1, boff = boff_of(s);
+        const bool next_b = tap == 8 && slice + 1 < nslices;
+        const bool more = s + 1 < nsteps;
+        // the activation registers (loaded nine steps ago) go to the other B image before the barrier of this step
+        if (next_b) stash_b((slice + 1) & 1);
+        // ---- blocks 0..3 ----
+        load_b(bbuf, boff + 1 * CS_BLD, std::integral_constant<int, (P + 1) & 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        if (dxc != 0) block(std::integral_constant<int, 0>{}, p_tag, std::integral_constant<int, P>{});
+        load_b(bbuf, boff + 2 * CS_BLD, std::integral_constant<int, P>{});
+        __builtin_amdgcn_sched_barrier(0);
+        block(std::integral_constant<int, 1>{}, p_tag, std::integral_constant<int, (P + 1) & 1>{});
+        load_b(bbuf, boff + 3 * CS_BLD, std::integral_constant<int, (P + 1) & 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        block(std::integral_constant<int, 2>{}, p_tag, std::integral_constant<int, P>{});
+        load_b(bbuf, boff + 4 * CS_BLD, std::integral_constant<int, P>{});
+        __builtin_amdgcn_sched_barrier(0);
+        block(std::integral_constant<int, 3>{}, p_tag, std::integral_constant<int, (P + 1) & 1>{});
+        __syncthreads();        // vmcnt(0): the DMA of step s+1 (a step old) has landed; buffer s&1 is free
+        if (s + 2 < nsteps) dma_a(s + 2, s & 1);
+        if (next_b && slice + 2 < nslices) fetch_b(slice + 2);
+        if (more) load_a((s + 1) & 1, std::integral_constant<int, (P + 1) & 1>{});
+        // ---- blocks 4..6, and the first fragment of the next step ----
+        load_b(bbuf, boff + 5 * CS_BLD, std::integral_constant<int, (P + 1) & 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        block(std::integral_constant<int, 4>{}, p_tag, std::integral_constant<int, P>{});
+        load_b(bbuf, boff + 6 * CS_BLD, std::integral_constant<int, P>{});
+        __builtin_amdgcn_sched_barrier(0);
+        block(std::integral_constant<int, 5>{}, p_tag, std::integral_constant<int, (P + 1) & 1>{});
+        if (more) load_b(((s + 1) / 9) & 1, boff_of(s + 1), std::integral_constant<int, (P + 1) & 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        if (dxc != 2) block(std::integral_constant<int, 6>{}, p_tag, std::integral_constant<int, P>{});
+    };
 
-    // ---- pipeline: A by LDS-DMA, double-buffered per step (tap inner); B double-buffered per 9-step slice ----
     fetch_b(0);
     stash_b(0);
     dma_a(0, 0);
     if (nslices > 1) fetch_b(1);
     __syncthreads();                                    // vmcnt(0): step 0's weights have landed
-    int abuf = 0;
-    for (int s = 0; s < nsteps; ++s) {
-        const int tap = s % 9, slice = s / 9;
-        const bool next_b = tap == 8 && slice + 1 < nslices;
-        // the activation registers (loaded nine steps ago) are consumed BEFORE this step's DMA goes out: the compiler
-        // waits vmcnt(0) at a use of an ordinary load's result while an LDS-DMA is outstanding
-        if (next_b && !(d.dbg & 4)) stash_b((slice + 1) & 1);
-        if (s + 1 < nsteps && !(d.dbg & 8)) dma_a(s + 1, abuf ^ 1);     // the other buffer: its readers passed the last barrier
-        if (next_b && slice + 2 < nslices && !(d.dbg & 4)) fetch_b(slice + 2);
-        __builtin_amdgcn_sched_barrier(0);
-        if (!(d.dbg & 2)) {
-            const int dy = tap / 3 - 1;
-            mma(abuf, slice & 1, dy, tap - (tap / 3) * 3);
-        }
-        __syncthreads();                                // retires the DMA (vmcnt(0)) and frees buffer abuf
-        abuf ^= 1;
+    if (nsteps > 1) dma_a(1, 1);
+    load_a(0, std::integral_constant<int, 0>{});
+    load_b(0, boff_of(0), std::integral_constant<int, 0>{});
+    int s = 0;
+    for (; s + 1 < nsteps; s += 2) {
+        step(s, std::integral_constant<int, 0>{});
+        step(s + 1, std::integral_constant<int, 1>{});
     }
+    if (s < nsteps) step(s, std::integral_constant<int, 0>{});
 
     if (d.dbg & 1) { if (acc[0][0][0] == 123.456f) epi.store_rb(0, 0, 0, acc[1][1][1], true, 0.f); return; }
     // ---- epilogue: D layout lane -> image row l15 (all 7 columns: one per block), output channels 4*lq + r ----
