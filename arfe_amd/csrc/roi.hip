@@ -1,6 +1,7 @@
 // AR-RFF RoI-side kernels: enlarged-RoI generation, RoI -> level assignment (bit-exact), RoIAlign v2
 // forward/backward fused with the per-level dispatch, and the elementwise fusion z = ori + ori*(lw+lh).
 #include "common.hpp"
+#include <type_traits>
 
 namespace arfe {
 
@@ -453,6 +454,9 @@ __global__ __launch_bounds__(256) void roialign_fwd_sep_kernel(RoiLevels L, RoiS
         if (tid < hn) wyT_s[tid][7] = 0.f;
     }
     __syncthreads();
+#if defined(ARFE_PROBES) && defined(ARFE_RF_PROBE) && (ARFE_RF_PROBE & 8)
+    if (wyT_s[1][1] != 123.456f) return;
+#endif
     const int wext = h_s.wext, hext = h_s.hext;
     // A lane is one window column; narrow windows put 4 (<= 16 columns) or 2 (<= 32) channels on one wave, so that a
     // row read (one dword per lane: it costs the address unit as much as a 16-byte one) carries several channels.
@@ -504,18 +508,27 @@ __global__ __launch_bounds__(256) void roialign_fwd_sep_kernel(RoiLevels L, RoiS
     for (int cb = wave * pack; cb < ncc; cb += 4 * pack) {
         const int c = cb + half;
         const FT* f = feat + (((int64_t)bimg * L.C + c0 + (c < ncc ? c : cb)) * H + h_s.y0) * W + h_s.x0 + colc;
+        // (bins in pairs as v_pk_fma_f32 - 4 instead of 7 FMAs per row - measured SLOWER: 301 -> 317 us)
         float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         for (int y = 0; y < hext; y += RF_ROWS) {
             float v[RF_ROWS];
 #pragma unroll
+#if defined(ARFE_PROBES) && defined(ARFE_RF_PROBE) && (ARFE_RF_PROBE & 1)
+            for (int j = 0; j < RF_ROWS; ++j) v[j] = (float)(lane + y + j);
+#else
             for (int j = 0; j < RF_ROWS; ++j) v[j] = (float)f[(int64_t)(y + j < hext ? y + j : hext - 1) * W];
+#endif
             // rows past the window (y + j >= hext) carry zero weight in the table: no branch per row
 #pragma unroll
             for (int j = 0; j < RF_ROWS; ++j) {
+#if defined(ARFE_PROBES) && defined(ARFE_RF_PROBE) && (ARFE_RF_PROBE & 2)
+                acc[j % 7] += v[j];
+#else
                 const float4_u wa = *reinterpret_cast<const float4_u*>(&wyT_s[y + j][0]);
                 const float4_u wb = *reinterpret_cast<const float4_u*>(&wyT_s[y + j][4]);
                 acc[0] += wa[0] * v[j]; acc[1] += wa[1] * v[j]; acc[2] += wa[2] * v[j]; acc[3] += wa[3] * v[j];
                 acc[4] += wb[0] * v[j]; acc[5] += wb[1] * v[j]; acc[6] += wb[2] * v[j];
+#endif
             }
         }
 #pragma unroll
@@ -525,7 +538,11 @@ __global__ __launch_bounds__(256) void roialign_fwd_sep_kernel(RoiLevels L, RoiS
         for (int hh = 0; hh < pack; ++hh) {
             if (lane < 49 && cb + hh < ncc) {
                 float acc2 = 0.f;
+#if defined(ARFE_PROBES) && defined(ARFE_RF_PROBE) && (ARFE_RF_PROBE & 4)
+                acc2 = U_s[wave][qph][hh * pw_cols + xlo];
+#else
                 for (int x = xlo; x < xhi; ++x) acc2 += U_s[wave][qph][hh * pw_cols + x] * wx_s[qpw][x];
+#endif
                 obase[(cb + hh) * 49 + lane] = (OT)acc2;
             }
         }
@@ -644,10 +661,14 @@ __global__ __launch_bounds__(256) void roialign_bwd_tiles_kernel(RoiLevels L, Ro
     // every thread copies up to RB_GPT floats of each RoI's 16x49 gradient block
     const bool a_role = tid < RT * 7 || (tid >= 128 && tid < 128 + RT * 7);
     const int a_axis = tid >> 7, a_u = tid & 127, a_r = a_u / 7, a_pb = a_u - a_r * 7;
-    constexpr int RB_GPT = (RB_CC * 49 + 255) / 256;      // 4
+    // float gradients: one element per load; half gradients: PAIRS as 32-bit words (two-byte loads write half a register
+    // and serialise: 562 us against 366 us for the float kernel; as words 2 x fewer loads than the float kernel issues)
+    constexpr bool GH = sizeof(GT) == 2;
+    constexpr int RB_GPT = GH ? (RB_CC * 49 / 2 + 255) / 256 : (RB_CC * 49 + 255) / 256;      // 4 | 7
     // register prefetch of one batch: the dependent global reads (list -> header -> table, gradients) of batch n+1
     // are in flight while batch n is contracted
-    float pw[RB_NB], pg[RB_NB][RB_GPT];
+    float pw[RB_NB];
+    typename std::conditional<GH, unsigned, float>::type pg[RB_NB][RB_GPT];
     // software pipeline of the dependent reads: RoI ids two batches ahead, header -> table / gradients one batch ahead
     int ids[RB_NB], metas[RB_NB];
     auto fetch_ids = [&](int e0) {
@@ -663,7 +684,7 @@ __global__ __launch_bounds__(256) void roialign_bwd_tiles_kernel(RoiLevels L, Ro
         for (int j = 0; j < RB_NB; ++j) {
             pw[j] = 0.f;
 #pragma unroll
-            for (int i = 0; i < RB_GPT; ++i) pg[j][i] = 0.f;
+            for (int i = 0; i < RB_GPT; ++i) pg[j][i] = 0;
             if (j >= nb) continue;
             const int id = ids[j];
             // set index without a division (RB_MAXSETS = 4; an integer division is ~20 vector instructions, per RoI and lane)
@@ -683,10 +704,29 @@ __global__ __launch_bounds__(256) void roialign_bwd_tiles_kernel(RoiLevels L, Ro
                 pw[j] = w;
             }
             const GT* gp = gout + (int64_t)k * g_roi_stride + ((int64_t)s * L.C + c0) * 49;
+            if constexpr (GH) {
+                const int n = ncc * 49;
+                const bool aligned = (reinterpret_cast<uintptr_t>(gp) & 3) == 0;      // block-uniform
 #pragma unroll
-            for (int i = 0; i < RB_GPT; ++i) {
-                const int q = tid + 256 * i;
-                if (q < ncc * 49) pg[j][i] = (float)gp[q];
+                for (int i = 0; i < RB_GPT; ++i) {
+                    const int q = 2 * (tid + 256 * i);
+                    if (aligned && q + 1 < n) pg[j][i] = *reinterpret_cast<const unsigned*>(gp + q);
+                    else {
+                        const unsigned lo = q < n ? (unsigned)reinterpret_cast<const unsigned short*>(gp)[q] : 0u;
+                        const unsigned hi = q + 1 < n ? (unsigned)reinterpret_cast<const unsigned short*>(gp)[q + 1] : 0u;
+                        pg[j][i] = lo | (hi << 16);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < RB_GPT; ++i) {
+                    const int q = tid + 256 * i;
+#if defined(ARFE_PROBES) && defined(ARFE_RB_PROBE) && (ARFE_RB_PROBE & 2)
+                    if (q < ncc * 49) pg[j][i] = (float)(q + id);
+#else
+                    if (q < ncc * 49) pg[j][i] = (float)gp[q];
+#endif
+                }
             }
         }
     };
@@ -700,10 +740,22 @@ __global__ __launch_bounds__(256) void roialign_bwd_tiles_kernel(RoiLevels L, Ro
             if (a_role) { if (a_axis) wx_s[j][rb_wrow(a_r) + a_pb] = pw[j]; else wy_s[j][rb_wrow(a_r) + a_pb] = pw[j]; }
 #pragma unroll
             for (int i = 0; i < RB_GPT; ++i) {
-                const int q = tid + 256 * i;
-                if (q < RB_CC * 49) {
-                    const int c = q / 49, r2 = q - c * 49, ph = r2 / 7;
-                    G_s[j][c][ph * 8 + r2 - ph * 7] = pg[j][i];
+                if constexpr (GH) {
+                    const int q = 2 * (tid + 256 * i);
+                    if (q < RB_CC * 49) {          // RB_CC * 49 is even: both halves of the word are inside the chunk
+                        typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+                        const h2_t h = __builtin_bit_cast(h2_t, pg[j][i]);
+                        const int c = q / 49, r2 = q - c * 49, ph = r2 / 7;
+                        G_s[j][c][ph * 8 + r2 - ph * 7] = (float)h[0];
+                        const int q1 = q + 1, c1 = q1 / 49, r21 = q1 - c1 * 49, ph1 = r21 / 7;
+                        G_s[j][c1][ph1 * 8 + r21 - ph1 * 7] = (float)h[1];
+                    }
+                } else {
+                    const int q = tid + 256 * i;
+                    if (q < RB_CC * 49) {
+                        const int c = q / 49, r2 = q - c * 49, ph = r2 / 7;
+                        G_s[j][c][ph * 8 + r2 - ph * 7] = pg[j][i];
+                    }
                 }
             }
         }
@@ -755,6 +807,9 @@ __global__ __launch_bounds__(256) void roialign_bwd_tiles_kernel(RoiLevels L, Ro
                     if (nseg == 1) *dst = acc[c][r];
                     else unsafeAtomicAdd(dst, acc[c][r]);
                 } else {
+#if defined(ARFE_PROBES) && defined(ARFE_RB_PROBE) && (ARFE_RB_PROBE & 1)
+                    if (acc[c][r] == 123.456f)
+#endif
                     *dst = (DT)acc[c][r];          // (half maps: the host never slices RoI lists, every tile is stored once)
                 }
             }

@@ -95,6 +95,7 @@ def _ws(nbytes, device):
 
 
 _side_stream = {}
+_ONE_STREAM = os.environ.get('ARFE_ONE_STREAM', '0') == '1'      # measurement aid: everything on the current stream
 
 
 def side_stream(device):
@@ -112,6 +113,8 @@ def on_side(device, fn):
     """Run fn() on the side stream, ordered after everything already enqueued on the current stream."""
     if device.type != "cuda":
         raise hip.ArfeHipError(f"expected tensors on the GPU, got device {device} (there is no CPU path)")
+    if _ONE_STREAM:
+        return fn()
     main = torch.cuda.current_stream()
     side = side_stream(device)
     side.wait_stream(main)
@@ -120,6 +123,8 @@ def on_side(device, fn):
 
 
 def join_side(device):
+    if _ONE_STREAM:
+        return
     torch.cuda.current_stream().wait_stream(side_stream(device))
 
 
