@@ -285,6 +285,19 @@ def batched_nms(bboxes, scores, inds, nms_cfg, class_agnostic=False):
         raise NotImplementedError(f"nms type {kind}: the harness implements hard NMS")
     if bboxes.numel() == 0:
         return torch.cat([bboxes, scores[:, None]], -1), bboxes.new_zeros(0, dtype=torch.long)
-    shifted = bboxes if class_agnostic else bboxes + (inds.to(bboxes) * (bboxes.max() + 1))[:, None]
-    dets, keep = nms(torch.cat([shifted, scores[:, None]], -1), **cfg)
-    return torch.cat([bboxes[keep], dets[:, -1:]], -1), keep
+    if class_agnostic:
+        dets, keep = nms(torch.cat([bboxes, scores[:, None]], -1), **cfg)
+        return torch.cat([bboxes[keep], dets[:, -1:]], -1), keep
+    # The reference shifts every group into its own coordinate range and runs ONE greedy pass over all boxes; boxes of
+    # different groups can then never suppress each other, so the same result comes from one pass PER GROUP on the shifted
+    # coordinates (same arithmetic) - the all-pairs IoU of 5 x 2000 RPN boxes is 5 x [2000, 2000] instead of [10000, 10000].
+    shifted = bboxes + (inds.to(bboxes) * (bboxes.max() + 1))[:, None]
+    kept = []
+    for g in torch.unique(inds).tolist():
+        sel = torch.nonzero(inds == g, as_tuple=False).squeeze(1)
+        _, k = nms(torch.cat([shifted[sel], scores[sel, None]], -1), **cfg)
+        kept.append(sel[k])
+    keep = torch.cat(kept).sort()[0]
+    # descending score, ties by ascending index: the order of the single pass (stable sort of the scores)
+    keep = keep[scores[keep].sort(descending=True, stable=True)[1]]
+    return torch.cat([bboxes[keep], scores[keep, None]], -1), keep

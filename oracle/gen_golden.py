@@ -352,6 +352,62 @@ def _boxes(n, w, h, gen, lo=4.0, hi=120.0):
     return torch.cat([xy, xy + wh], 1)
 
 
+def head_train_case():
+    """Fixtures for the training side of BBoxHead and the RandomSampler, from the reference's own classes: two images, an
+    R-CNN assignment each, sampling under a fixed torch seed (both implementations draw torch.randperm the same way),
+    targets, losses (class-specific and class-agnostic regression), per-class regression and the Cascade refinement."""
+    import types as _t
+    from oracle.ref_loader import load_reference_head_train
+    R = load_reference_head_train()
+    g = torch.Generator().manual_seed(77)
+    nc = 6
+    d = {}
+    assigner = R.MaxIoUAssigner(pos_iou_thr=0.5, neg_iou_thr=0.5, min_pos_iou=0.5, match_low_quality=False, ignore_iof_thr=-1)
+    sampler = R.RandomSampler(num=64, pos_fraction=0.25, neg_pos_ub=-1, add_gt_as_proposals=True)
+    results, rois = [], []
+    for i in range(2):
+        gts = _boxes(7 + i, 96, 64, g)
+        labels = torch.randint(0, nc, (gts.shape[0], ), generator=g)
+        jit = torch.randn(40, 4, generator=g) * 2.0
+        props = torch.cat([_boxes(120, 96, 64, g), gts.repeat(6, 1)[:40] + jit])
+        d[f'ht_gts{i}'], d[f'ht_labels{i}'], d[f'ht_props{i}'] = gts, labels, props
+        a = assigner.assign(props, gts, None, labels)
+        torch.manual_seed(1000 + i)
+        r = sampler.sample(a, props, gts, labels)
+        d[f'ht_pos_inds{i}'], d[f'ht_neg_inds{i}'] = r.pos_inds, r.neg_inds
+        d[f'ht_pos_is_gt{i}'], d[f'ht_pos_assigned{i}'] = r.pos_is_gt, r.pos_assigned_gt_inds
+        d[f'ht_pos_bboxes{i}'], d[f'ht_neg_bboxes{i}'] = r.pos_bboxes, r.neg_bboxes
+        results.append(r)
+        rois.append(torch.cat([torch.full((r.bboxes.shape[0], 1), float(i)), r.bboxes], 1))
+    rois = torch.cat(rois)
+    d['ht_rois'] = rois
+    cfg = _t.SimpleNamespace(pos_weight=-1)
+    coder = dict(type='DeltaXYWHBBoxCoder', target_means=[0., 0., 0., 0.], target_stds=[0.1, 0.1, 0.2, 0.2])
+    for tag, agnostic in (('cs', False), ('ag', True)):
+        head = R.BBoxHead(with_avg_pool=False, with_cls=True, with_reg=True, roi_feat_size=7, in_channels=2, num_classes=nc,
+                          bbox_coder=coder, reg_class_agnostic=agnostic,
+                          loss_cls=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0),
+                          loss_bbox=dict(type='SmoothL1Loss', beta=1.0, loss_weight=1.0))
+        t = head.get_targets(results, None, None, cfg)
+        if not agnostic:
+            d['ht_t_labels'], d['ht_t_label_weights'], d['ht_t_bbox_targets'], d['ht_t_bbox_weights'] = t
+        n = rois.shape[0]
+        cls = torch.randn(n, nc + 1, generator=g)
+        reg = torch.randn(n, 4 if agnostic else 4 * nc, generator=g) * 0.3
+        d[f'ht_{tag}_cls'], d[f'ht_{tag}_reg'] = cls, reg
+        losses = head.loss(cls, reg, rois, *t)
+        d[f'ht_{tag}_loss_cls'], d[f'ht_{tag}_loss_bbox'], d[f'ht_{tag}_acc'] = losses['loss_cls'], losses['loss_bbox'], losses['acc']
+        metas = [dict(img_shape=(64, 96, 3)), dict(img_shape=(64, 96, 3))]
+        # Cascade: the regressor's class is the predicted one where the target is background (cascade_roi_head.py:262-266)
+        roi_labels = torch.where(t[0] == nc, cls[:, :-1].argmax(1), t[0])
+        d[f'ht_{tag}_roi_labels'] = roi_labels
+        one = head.regress_by_class(rois[:9], roi_labels[:9], reg[:9], metas[0])
+        d[f'ht_{tag}_regress'] = one
+        refined = head.refine_bboxes(rois, roi_labels, reg, [r.pos_is_gt for r in results], metas)
+        d[f'ht_{tag}_refined0'], d[f'ht_{tag}_refined1'] = refined
+    return d
+
+
 def harness_case():
     """Fixtures of the detector harness from the reference's own box / anchor / loss code."""
     from oracle.ref_loader import load_reference_harness
@@ -415,6 +471,7 @@ def harness_case():
     d['reg_pred'], d['reg_target'], d['reg_weight'] = rp, rt, rw
     d['l1'] = hs.L1Loss(loss_weight=1.0)(rp, rt, rw, avg_factor=512.0)
     d['smooth_l1'] = hs.SmoothL1Loss(beta=1.0 / 9.0, loss_weight=1.0)(rp, rt, rw, avg_factor=512.0)
+    d.update(head_train_case())
     np.savez_compressed(os.path.join(OUT, 'harness.npz'), **npd(d))
     print('harness.npz', {k: tuple(v.shape) for k, v in d.items() if hasattr(v, 'shape')})
 

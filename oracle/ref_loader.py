@@ -244,6 +244,41 @@ def load_reference_harness():
         CrossEntropyLoss=ce.CrossEntropyLoss, L1Loss=l1.L1Loss, SmoothL1Loss=l1.SmoothL1Loss, accuracy=acc.accuracy)
 
 
+def load_reference_head_train():
+    """The training side of the reference's BBoxHead (`_get_target_single`, `get_targets`, `loss`, `regress_by_class`,
+    `refine_bboxes`: bbox_head.py:86-352) and its samplers (core/bbox/samplers/{sampling_result, base_sampler,
+    random_sampler}.py), for the detector-harness fixtures.  bbox_head.py binds `build_bbox_coder`, `build_loss`,
+    `multi_apply` and `accuracy` from packages that are stand-ins here: they are pointed at the reference's own coder / loss
+    classes (load_reference_harness); `multi_apply` (core/utils/misc.py, which imports mmcv) is its three-line map / zip."""
+    import functools
+    hs = load_reference_harness()
+    ref = load_reference()
+    bh = sys.modules['mmdet.models.roi_heads.bbox_heads.bbox_head']
+
+    def build_bbox_coder(cfg):
+        cfg = dict(cfg)
+        kind = cfg.pop('type')
+        assert kind == 'DeltaXYWHBBoxCoder', kind
+        return hs.DeltaXYWHBBoxCoder(**cfg)
+
+    def build_loss(cfg):
+        cfg = dict(cfg)
+        return {'CrossEntropyLoss': hs.CrossEntropyLoss, 'SmoothL1Loss': hs.SmoothL1Loss, 'L1Loss': hs.L1Loss}[cfg.pop('type')](**cfg)
+
+    def multi_apply(func, *args, **kwargs):
+        pfunc = functools.partial(func, **kwargs) if kwargs else func
+        return tuple(map(list, zip(*map(pfunc, *args))))
+
+    bh.build_bbox_coder, bh.build_loss, bh.multi_apply, bh.accuracy = build_bbox_coder, build_loss, multi_apply, hs.accuracy
+    _mod('mmdet.core.bbox.samplers')
+    sys.modules['mmdet.core.bbox'].demodata = _load('mmdet.core.bbox.demodata', 'mmdet/core/bbox/demodata.py')   # RandomSampler's rng helper
+    sr = _load('mmdet.core.bbox.samplers.sampling_result', 'mmdet/core/bbox/samplers/sampling_result.py')
+    _load('mmdet.core.bbox.samplers.base_sampler', 'mmdet/core/bbox/samplers/base_sampler.py')
+    rs = _load('mmdet.core.bbox.samplers.random_sampler', 'mmdet/core/bbox/samplers/random_sampler.py')
+    return types.SimpleNamespace(BBoxHead=ref.BBoxHead, RandomSampler=rs.RandomSampler, SamplingResult=sr.SamplingResult,
+                                 MaxIoUAssigner=hs.MaxIoUAssigner)
+
+
 def load_reference_roi_align():
     """The compiled reference RoIAlign (oracle/_ref, built by oracle/build_ref.py)."""
     here = os.path.dirname(os.path.abspath(__file__))
