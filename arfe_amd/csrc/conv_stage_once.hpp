@@ -216,6 +216,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stage_once_kernel(ConvStageDim
         if (dxc != 2) block(std::integral_constant<int, 6>{}, p_tag, std::integral_constant<int, P>{});
     };
 
+#if defined(ARFE_PROBES) && defined(ARFE_CLOCK_PROBE)
+    const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     fetch_b(0);
     stash_b(0);
     dma_a(0, 0);
@@ -231,6 +234,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stage_once_kernel(ConvStageDim
     }
     if (s < nsteps) step(s, std::integral_constant<int, 0>{});
 
+#if defined(ARFE_PROBES) && defined(ARFE_CLOCK_PROBE)
+    if (tid == 0 && (blockIdx.x % 37) == 0) {        // in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz (MI355X_MICROARCH.md)
+        const unsigned long long dt = __builtin_amdgcn_s_memtime() - clk_t0, dr = __builtin_amdgcn_s_memrealtime() - clk_r0;
+        printf("clk wg %d: %llu core cycles in %llu x 10 ns -> %.0f MHz\n", (int)blockIdx.x, dt, dr, dr ? 100.0 * (double)dt / (double)dr : 0.0);
+    }
+#endif
     if (d.dbg & 1) { if (acc[0][0][0] == 123.456f) epi.store_rb(0, 0, 0, acc[1][1][1], true, 0.f); return; }
     // ---- epilogue: D layout lane -> image row l15 (all 7 columns: one per block), output channels 4*lq + r ----
     float rbias[4][4];
