@@ -219,9 +219,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stage_once_kernel(ConvStageDim
 #if defined(ARFE_PROBES) && defined(ARFE_CLOCK_PROBE)
     const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
+    dma_a(0, 0);                                        // the first weight tile and the first activation slice: one round trip, not two
     fetch_b(0);
     stash_b(0);
-    dma_a(0, 0);
     if (nslices > 1) fetch_b(1);
     __syncthreads();                                    // vmcnt(0): step 0's weights have landed
     if (nsteps > 1) dma_a(1, 1);
