@@ -940,11 +940,13 @@ extern "C" int32_t arfe_nonlocal_bwd_wout(int32_t B, int32_t C, int32_t L, const
     return ARFE_OK;
 }
 
-// the data path: dm = dbsf + [Wt;Wp;Wg]^T d(tpg); leaves d(tpg) in the workspace for arfe_nonlocal_bwd_wcat
-extern "C" int32_t arfe_nonlocal_bwd_data(int32_t B, int32_t C, int32_t L, const float* dbsf, const float* w_theta,
-                                          const float* w_phi, const float* w_g, const float* w_out, const float* tpg,
-                                          const float* P, const float* y, float* dP, float* dm, void* workspace,
-                                          void* stream) {
+// the data path: dm = dbsf + [Wt;Wp;Wg]^T d(tpg); leaves d(tpg) in the workspace for arfe_nonlocal_bwd_wcat.
+// parts: 1 = everything up to d(tpg) (the three projections' gradients), 2 = the last contraction (dm), 3 = both.  After part 1 the
+// parameter gradients (arfe_nonlocal_bwd_wcat) have all they need: a caller starts them on another stream BEFORE part 2.
+static int32_t nl_bwd_data_parts(int32_t B, int32_t C, int32_t L, const float* dbsf, const float* w_theta,
+                                 const float* w_phi, const float* w_g, const float* w_out, const float* tpg,
+                                 const float* P, const float* y, float* dP, float* dm, void* workspace,
+                                 void* stream, int parts) {
     ARFE_CHECK_ARG(B > 0 && C > 0 && L > 0 && L <= 256 * NL_ROW_REGS, ARFE_ERR_ARG, "nonlocal_bwd: bad shape");
     ARFE_CHECK_ARG(dbsf && w_theta && w_phi && w_g && w_out && tpg && P && y && dP && dm && workspace, ARFE_ERR_ARG,
                    "nonlocal_bwd: null pointer");
@@ -952,10 +954,11 @@ extern "C" int32_t arfe_nonlocal_bwd_data(int32_t B, int32_t C, int32_t L, const
     const int64_t CL = (int64_t)C * L, LL = (int64_t)L * L;
     const NlWs ws = nl_ws(workspace, B, C, L);
     float *wcat = ws.wcat, *dtpg = ws.dtpg, *dy = ws.dy, *delta = ws.delta;
+    int32_t rc;
+    if (parts & 1) {
     hipLaunchKernelGGL(nl_pack_kernel, dim3(cdiv(3 * C * C, 256)), dim3(256), 0, st, w_theta, w_phi, w_g,
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, wcat, (float*)nullptr, C);
     ARFE_CHECK_LAUNCH();
-    int32_t rc;
     {
         ZeroList z;
         z.add(dtpg, (int64_t)B * 3 * CL);
@@ -1001,7 +1004,8 @@ extern "C" int32_t arfe_nonlocal_bwd_data(int32_t B, int32_t C, int32_t L, const
         rc = gemm_autosplit(C, L, L, 1, B, la, lb, e, 0, st, nl_slab_base(workspace, B, C, L), nl_slab_floats(B, C, L));
         if (rc) return rc;
     }
-    {   // dm[z] = dbsf[z] + wcat^T . dtpg[z]
+    }
+    if (parts & 2) {   // dm[z] = dbsf[z] + wcat^T . dtpg[z]
         LoadRowMajorI la{wcat, 0, 0, C, C, 3 * C};
         LoadRowMajorI lb{dtpg, 3 * CL, 0, L, L, 3 * C};
         EpiPlain e = epi_plain(dm, CL, L);
@@ -1010,6 +1014,25 @@ extern "C" int32_t arfe_nonlocal_bwd_data(int32_t B, int32_t C, int32_t L, const
         if (rc) return rc;
     }
     return ARFE_OK;
+}
+extern "C" int32_t arfe_nonlocal_bwd_data(int32_t B, int32_t C, int32_t L, const float* dbsf, const float* w_theta,
+                                          const float* w_phi, const float* w_g, const float* w_out, const float* tpg,
+                                          const float* P, const float* y, float* dP, float* dm, void* workspace,
+                                          void* stream) {
+    return nl_bwd_data_parts(B, C, L, dbsf, w_theta, w_phi, w_g, w_out, tpg, P, y, dP, dm, workspace, stream, 3);
+}
+// arfe_nonlocal_bwd_data in two calls (same arguments): _dtpg leaves d(theta, phi, g) in the workspace, _dm finishes dm.
+extern "C" int32_t arfe_nonlocal_bwd_dtpg(int32_t B, int32_t C, int32_t L, const float* dbsf, const float* w_theta,
+                                          const float* w_phi, const float* w_g, const float* w_out, const float* tpg,
+                                          const float* P, const float* y, float* dP, float* dm, void* workspace,
+                                          void* stream) {
+    return nl_bwd_data_parts(B, C, L, dbsf, w_theta, w_phi, w_g, w_out, tpg, P, y, dP, dm, workspace, stream, 1);
+}
+extern "C" int32_t arfe_nonlocal_bwd_dm(int32_t B, int32_t C, int32_t L, const float* dbsf, const float* w_theta,
+                                        const float* w_phi, const float* w_g, const float* w_out, const float* tpg,
+                                        const float* P, const float* y, float* dP, float* dm, void* workspace,
+                                        void* stream) {
+    return nl_bwd_data_parts(B, C, L, dbsf, w_theta, w_phi, w_g, w_out, tpg, P, y, dP, dm, workspace, stream, 2);
 }
 
 // dw / db of theta, phi, g from the d(tpg) the data path left in the workspace

@@ -307,11 +307,15 @@ def nonlocal_bwd_op(dbsf, m, wt, wp, wg, wo, saved, split_streams=False):
     L_ = hip.lib()
     on_side(dev, lambda: check(L_.arfe_nonlocal_bwd_wout(B, C, L, ptr(dbsf), ptr(y), ptr(dwo), ptr(dbo), stream()),
                                "arfe_nonlocal_bwd_wout"))
+    args = (B, C, L, ptr(dbsf), ptr(wt), ptr(wp), ptr(wg), ptr(wo), ptr(tpg), ptr(P), ptr(y), ptr(dP), ptr(dm), ptr(ws))
     with probe('nonlocal_bwd'):
-        check(L_.arfe_nonlocal_bwd_data(B, C, L, ptr(dbsf), ptr(wt), ptr(wp), ptr(wg), ptr(wo), ptr(tpg), ptr(P), ptr(y),
-                                        ptr(dP), ptr(dm), ptr(ws), stream()), "arfe_nonlocal_bwd_data")
+        check(L_.arfe_nonlocal_bwd_dtpg(*args, stream()), "arfe_nonlocal_bwd_dtpg")
+    # the projections' parameter gradients need d(theta, phi, g) only: they go to the side stream BEFORE the last contraction
+    # of the data path is enqueued (behind it they were the last kernel of the step to finish)
     on_side(dev, lambda: check(L_.arfe_nonlocal_bwd_wcat(B, C, L, ptr(m), ptr(dwt), ptr(dbt), ptr(dwp), ptr(dbp), ptr(dwg),
                                                          ptr(dbg), ptr(ws), stream()), "arfe_nonlocal_bwd_wcat"))
+    with probe('nonlocal_bwd'):
+        check(L_.arfe_nonlocal_bwd_dm(*args, stream()), "arfe_nonlocal_bwd_dm")
     # (ws, dP and the outputs were allocated on the current stream and are used on the side stream: the caller's join
     # orders every later use; record_stream keeps the allocator from re-issuing them before the side stream is through)
     side_reads(dev, ws, dP, dbsf, y, m, dwt, dbt, dwp, dbp, dwg, dbg, dwo, dbo)

@@ -57,6 +57,8 @@ SIGNATURES = {
     "arfe_nonlocal_bwd": (_i32, [_i32, _i32, _i32] + [_vp] * 21),
     "arfe_nonlocal_bwd_wout": (_i32, [_i32, _i32, _i32] + [_vp] * 5),
     "arfe_nonlocal_bwd_data": (_i32, [_i32, _i32, _i32] + [_vp] * 12),
+    "arfe_nonlocal_bwd_dtpg": (_i32, [_i32, _i32, _i32] + [_vp] * 12),
+    "arfe_nonlocal_bwd_dm": (_i32, [_i32, _i32, _i32] + [_vp] * 12),
     "arfe_nonlocal_bwd_wcat": (_i32, [_i32, _i32, _i32] + [_vp] * 9),
     "arfe_rff_make_rois": (_i32, [_i32, _vp, _vp, _vp, _vp]),
     "arfe_map_roi_levels": (_i32, [_i32, _vp, _i32, _f32, _vp, _vp]),

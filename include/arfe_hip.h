@@ -149,6 +149,15 @@ int32_t arfe_nonlocal_bwd_wout(int32_t B, int32_t C, int32_t L, const float* dbs
 int32_t arfe_nonlocal_bwd_data(int32_t B, int32_t C, int32_t L, const float* dbsf, const float* w_theta,
                                const float* w_phi, const float* w_g, const float* w_out, const float* tpg, const float* P,
                                const float* y, float* dP, float* dm, void* workspace, void* stream);
+/* arfe_nonlocal_bwd_data in two calls with the same arguments (ABI 3): _dtpg runs everything up to the gradients of the three
+ * projections (left in the workspace: all that arfe_nonlocal_bwd_wcat needs, so a caller starts it on another stream here),
+ * _dm the last contraction. */
+int32_t arfe_nonlocal_bwd_dtpg(int32_t B, int32_t C, int32_t L, const float* dbsf, const float* w_theta,
+                               const float* w_phi, const float* w_g, const float* w_out, const float* tpg, const float* P,
+                               const float* y, float* dP, float* dm, void* workspace, void* stream);
+int32_t arfe_nonlocal_bwd_dm(int32_t B, int32_t C, int32_t L, const float* dbsf, const float* w_theta,
+                               const float* w_phi, const float* w_g, const float* w_out, const float* tpg, const float* P,
+                               const float* y, float* dP, float* dm, void* workspace, void* stream);
 int32_t arfe_nonlocal_bwd_wcat(int32_t B, int32_t C, int32_t L, const float* m, float* dw_theta, float* db_theta,
                                float* dw_phi, float* db_phi, float* dw_g, float* db_g, void* workspace, void* stream);
 
