@@ -105,6 +105,51 @@ struct EpiConv {       // y[r*roi_stride + co*49 + p] = act(v + bias[co]) * [mas
     }
 };
 template <> struct epi_has_rowbias<EpiConv> { static constexpr bool value = true; };
+// The second gating conv of the AR-RFF head with the fusion folded into its epilogue (multirois_bbox_head.py:172-181):
+//   lh = ReLU(v + bias)      z = ori + ori * (lw + lh)
+// lh and z share the layout [R][C][49]; ori is a channel slice of the [R, 3C, 7, 7] concat (its own RoI stride).
+struct EpiConvFuseZ {
+    float* lh; const float* bias; const float* ori; int64_t ori_roi_stride; const float* lw; float* z; int C;
+    __device__ __forceinline__ float row_bias(int m) const { return bias ? epi_ld(bias, m) : 0.f; }
+    __device__ __forceinline__ void store_rb(int, int m, int n, float v, bool, float b) const {
+        const int r = n / 49, p = n - r * 49;
+        const int64_t o = ((int64_t)r * C + m) * 49 + p;
+        const float h = fmaxf(v + b, 0.f), x0 = epi_ld(ori, (int64_t)r * ori_roi_stride + m * 49 + p);
+        lh[o] = h;
+        z[o] = x0 + x0 * (epi_ld(lw, o) + h);
+    }
+    __device__ __forceinline__ void operator()(int zz, int m, int n, float v, bool first) const { store_rb(zz, m, n, v, first, row_bias(m)); }
+    __device__ __forceinline__ void store_row7(int m, int n, float (&v)[7], float b) const {
+        typedef float __attribute__((ext_vector_type(4), aligned(4))) f4u;
+        typedef float __attribute__((ext_vector_type(2), aligned(4))) f2u;
+        typedef const f4u __attribute__((address_space(4)))* c4;
+        typedef const f2u __attribute__((address_space(4)))* c2;
+        const int r = n / 49, p = n - r * 49;
+        const int64_t o = ((int64_t)r * C + m) * 49 + p;
+        const float* qo = ori + (int64_t)r * ori_roi_stride + m * 49 + p;
+        const float* qa = lw + o;
+        const f4u o0 = *(c4)(uintptr_t)qo, a0 = *(c4)(uintptr_t)qa;
+        const f2u o1 = *(c2)(uintptr_t)(qo + 4), a1 = *(c2)(uintptr_t)(qa + 4);
+        const float o2 = epi_ld(qo, 6), a2 = epi_ld(qa, 6);
+        const float xo[7] = {o0[0], o0[1], o0[2], o0[3], o1[0], o1[1], o2};
+        const float xa[7] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a2};
+        float h[7], zz[7];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            h[j] = fmaxf(v[j] + b, 0.f);
+            zz[j] = xo[j] + xo[j] * (xa[j] + h[j]);
+        }
+        float* ph = lh + o;
+        float* pz = z + o;
+        *reinterpret_cast<f4u*>(ph) = f4u{h[0], h[1], h[2], h[3]};
+        *reinterpret_cast<f2u*>(ph + 4) = f2u{h[4], h[5]};
+        ph[6] = h[6];
+        *reinterpret_cast<f4u*>(pz) = f4u{zz[0], zz[1], zz[2], zz[3]};
+        *reinterpret_cast<f2u*>(pz + 4) = f2u{zz[4], zz[5]};
+        pz[6] = zz[6];
+    }
+};
+template <> struct epi_has_rowbias<EpiConvFuseZ> { static constexpr bool value = true; };
 }  // namespace arfe
 #include "conv_stage_once.hpp"
 #include "conv_wgrad_stage_once.hpp"
@@ -704,6 +749,27 @@ extern "C" int32_t arfe_conv3x3_fwd(int32_t R, int32_t C, const float* x, int64_
         if (launch_conv_stage_once(R, C, ph, fh, x, x_roi_stride, e, as_stream(stream), &rc_so)) return rc_so;
     }
     return launch_gemm_auto(C, R * 49, C, 9, 1, 1, la, lb, e, as_stream(stream), /*exact=*/false, /*kb_inner=*/true);
+}
+
+// lh = ReLU(conv(x; w) + b) and z = ori + ori * (lw + lh) in one launch: the AR-RFF head's second gating conv with the fusion
+// (arfe_rff_fuse_fwd) in its epilogue.  Same results as the two calls; falls back to them where the stage-once kernel does not apply.
+extern "C" int32_t arfe_conv3x3_fwd_fuse(int32_t R, int32_t C, const float* x, int64_t x_roi_stride, const void* packed,
+                                         const float* b, const float* ori, int64_t ori_roi_stride, const float* lw, float* lh,
+                                         float* z, void* stream) {
+    ARFE_CHECK_ARG(R >= 0 && C > 0, ARFE_ERR_ARG, "conv3x3_fwd_fuse: bad shape");
+    if (R == 0) return ARFE_OK;
+    ARFE_CHECK_ARG(x && packed && ori && lw && lh && z, ARFE_ERR_ARG, "conv3x3_fwd_fuse: null pointer");
+    {
+        const float* wp = (const float*)packed;
+        const unsigned short* ph = (const unsigned short*)(wp + (size_t)2 * 9 * C * C);
+        const unsigned short* fh = ph + (size_t)4 * 9 * C * C;
+        EpiConvFuseZ e{lh, b, ori, ori_roi_stride, lw, z, C};
+        int32_t rc_so;
+        if (launch_conv_stage_once(R, C, ph, fh, x, x_roi_stride, e, as_stream(stream), &rc_so)) return rc_so;
+    }
+    int32_t rc = arfe_conv3x3_fwd(R, C, x, x_roi_stride, packed, b, 1, lh, (int64_t)C * 49, stream);
+    if (rc) return rc;
+    return arfe_rff_fuse_fwd(R, C, ori, ori_roi_stride, lw, lh, z, stream);
 }
 
 extern "C" int32_t arfe_conv3x3_bwd_data(int32_t R, int32_t C, const void* packed, const float* dy,

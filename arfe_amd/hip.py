@@ -79,6 +79,7 @@ SIGNATURES = {
     "arfe_conv3x3_workspace_bytes": (_i64, [_i32]),
     "arfe_conv3x3_pack_weights": (_i32, [_i32, _vp, _vp, _vp]),
     "arfe_conv3x3_fwd": (_i32, [_i32, _i32, _vp, _i64, _vp, _vp, _i32, _vp, _i64, _vp]),
+    "arfe_conv3x3_fwd_fuse": (_i32, [_i32, _i32, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "arfe_conv3x3_bwd_data": (_i32, [_i32, _i32, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
     "arfe_conv3x3_bwd_weight": (_i32, [_i32, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
     "arfe_rff_fuse_fwd": (_i32, [_i32, _i32, _vp, _i64, _vp, _vp, _vp, _vp]),

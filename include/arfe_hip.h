@@ -267,6 +267,12 @@ int32_t arfe_conv3x3_pack_weights(int32_t C, const float* w, void* packed, void*
 /* y = act(conv(x; w) + b) */
 int32_t arfe_conv3x3_fwd(int32_t R, int32_t C, const float* x, int64_t x_roi_stride, const void* packed,
                          const float* b, int32_t relu, float* y, int64_t y_roi_stride, void* stream);
+/* ABI 3: the second gating conv of the AR-RFF head with the fusion in its epilogue (multirois_bbox_head.py:172-181):
+ *   lh = ReLU(conv(x; w) + b)     z = ori + ori * (lw + lh)
+ * = arfe_conv3x3_fwd(relu) followed by arfe_rff_fuse_fwd, one launch; lh and z are [R, C, 7, 7] contiguous. */
+int32_t arfe_conv3x3_fwd_fuse(int32_t R, int32_t C, const float* x, int64_t x_roi_stride, const void* packed,
+                              const float* b, const float* ori, int64_t ori_roi_stride, const float* lw, float* lh,
+                              float* z, void* stream);
 /* ReLU backward is folded into the PRODUCER of each gradient (epilogue masks), so dy is used as is.
  * dx = conv^T(dy) * [dx_mask > 0]   (dx_mask optional: the post-ReLU tensor that fed this conv's input, addressed
  * like dx with its own roi stride) */

@@ -656,6 +656,26 @@ def test_conv3x3_stage_once_kernel_matches_torch_cpu(Fn, dev, R, C):
     assert torch.isnan(dx[:, :C]).all() and torch.isnan(dx[:, 2 * C:]).all()      # neighbouring slices untouched
 
 
+@pytest.mark.parametrize('R,C', [(50, 64), (5, 96), (3, 32)])
+def test_conv3x3_fwd_fuse_equals_conv_then_fusion(Fn, dev, R, C):
+    """arfe_conv3x3_fwd_fuse (the fusion z = ori + ori (lw + lh) in the epilogue of the conv that produces lh) against the two
+    calls it stands for, on a channel slice of a [R, 3C, 7, 7] concat; (3, 32) takes the fallback inside the entry point."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(R, 3 * C, 7, 7, generator=g).to(dev)
+    w = (torch.randn(C, C, 3, 3, generator=g) * 0.05).to(dev)
+    b = (torch.randn(C, generator=g) * 0.1).to(dev)
+    lw = torch.relu(torch.randn(R, C, 7, 7, generator=g)).to(dev)
+    pk = Fn.conv3x3_pack_op(w)
+    rs = 3 * C * 49
+    lh_ref = Fn.conv3x3_fwd_op(x.data_ptr() + 4 * 2 * C * 49, rs, R, C, pk, b, True)
+    z_ref = torch.empty(R, C, 7, 7, device=dev)
+    from arfe_amd import hip
+    hip.check(hip.lib().arfe_rff_fuse_fwd(R, C, x.data_ptr(), rs, hip.ptr(lw), hip.ptr(lh_ref), hip.ptr(z_ref), hip.stream()), "fuse")
+    lh, z = Fn.conv3x3_fwd_fuse_op(x.data_ptr() + 4 * 2 * C * 49, rs, R, C, pk, b, x.data_ptr(), rs, lw)
+    assert torch.equal(lh, lh_ref)
+    assert (z - z_ref).abs().max().item() <= 1e-6 * max(1.0, z_ref.abs().max().item())
+
+
 @pytest.mark.parametrize('R,C', [(64, 128), (65, 128), (200, 256)])
 def test_conv3x3_wgrad_stage_once_kernel_matches_torch_cpu(Fn, dev, R, C):
     """The stage-once weight-gradient kernel (conv_wgrad_stage_once.hpp; C a multiple of 128, R >= 64): row slices of a
