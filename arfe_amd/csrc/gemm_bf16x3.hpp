@@ -453,7 +453,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x6_kernel(GemmDims d, LA la, 
         const int fsw = xs_swz(l31);     // fragment row bases are multiples of 32
         for (int s = s_begin; s < s_end; ++s) {
             const bool more = (s + 1 < s_end);
+#if defined(ARFE_PROBES) && defined(ARFE_X6_PROBE) && (ARFE_X6_PROBE & 4)
+            (void)more;
+#else
             if (more) fetch(s + 1);
+#endif
+#if defined(ARFE_PROBES) && defined(ARFE_X6_PROBE) && (ARFE_X6_PROBE & 2)
+            if (s < 0)
+#endif
 #pragma unroll
             for (int kk = 0; kk < XB_BK; kk += 16) {
                 bf16x8 a1[2], a2[2], a3[2], b1[2], b2[2], b3[2];
@@ -480,14 +487,19 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x6_kernel(GemmDims d, LA la, 
                     }
             }
             __syncthreads();
+#if !(defined(ARFE_PROBES) && defined(ARFE_X6_PROBE) && (ARFE_X6_PROBE & 4))
             if (more) {
                 stash();
                 __syncthreads();
             }
+#endif
         }
     } else if (!first_split) {
         return;
     }
+#if defined(ARFE_PROBES) && defined(ARFE_X6_PROBE) && (ARFE_X6_PROBE & 1)
+    if (acc[0][0][0] != 123.456f) return;
+#endif
 
     const int h = lane >> 5, l31 = lane & 31;
 #pragma unroll
