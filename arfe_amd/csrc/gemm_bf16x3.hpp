@@ -517,6 +517,146 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x6_kernel(GemmDims d, LA la, 
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// bf16x6, second generation (round 3).  Probes on the kernel above showed its three parts adding up (staging 53 us + MFMAs 74 +
+// epilogue 62 of 175 for the NonLocal logits): one LDS buffer and two barriers per K-step overlap nothing.  Here the K-step is
+// ONE MFMA k-slice (16), which halves the six operand images (128 rows x 32 B each: 24.6 KB per buffer), so that TWO buffers fit
+// beside a second workgroup (49 KB): the split + LDS stores of step s+1 and the global loads of step s+2 ride between the 24 MFMAs
+// of step s, one barrier per step.  The epilogue is the large tile's: the two column blocks of a wave exchange halves
+// (v_permlane32_swap) and every store covers 256 contiguous bytes.  LDS rows are 32 bytes; octet o of row r sits at
+// o ^ ((r >> 3) & 1) (conflict-free b128 fragment reads for lane = (row, k half)).
+constexpr int X6_BK = 16;
+constexpr int X6_IMG = GEMM_BM * X6_BK;                 // elements per operand image
+constexpr int X6_BUF = 6 * X6_IMG;
+constexpr int X6_LDS_BYTES = 2 * X6_BUF * 2;            // 49 152
+
+template <class LA, class LB, class EPI>
+__global__ __launch_bounds__(256, 2) void gemm_bf16x6v2_kernel(GemmDims d, LA la, LB lb, EPI epi) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short x6_lds[];
+    auto img = [&](int buf, int which) -> unsigned short* { return x6_lds + buf * X6_BUF + which * X6_IMG; };
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int z = blockIdx.z;
+
+    int ntiles = d.tiles_m * d.tiles_n;
+    int bid = blockIdx.x;
+    {
+        int q = ntiles >> 3, r = ntiles & 7, x = bid & 7, j = bid >> 3;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+    }
+    const int tm = bid / d.tiles_n, tn = bid % d.tiles_n;
+    const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
+
+    // d.ksteps_total counts steps of X6_BK here (set by the launcher)
+    const int ksteps_per_kb = (d.K + X6_BK - 1) / X6_BK;
+    const int per = (d.ksteps_total + d.splitk - 1) / d.splitk;
+    const int s_begin = blockIdx.y * per;
+    int s_end = s_begin + per;
+    if (s_end > d.ksteps_total) s_end = d.ksteps_total;
+    const bool first_split = (blockIdx.y == 0);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // staging: operand tile = 128 rows x 2 k-octets = 256 (row, octet) pairs: one per thread and operand
+    int a_row, a_oct, b_row, b_oct;
+    if (LA::kfast) { a_oct = tid & 1; a_row = tid >> 1; } else { a_row = tid & 127; a_oct = tid >> 7; }
+    if (LB::kfast) { b_oct = tid & 1; b_row = tid >> 1; } else { b_row = tid & 127; b_oct = tid >> 7; }
+    const typename LA::Row arow = la.row(z, m0 + a_row);
+    const typename LB::Row brow = lb.row(z, n0 + b_row);
+    const int a_off = a_row * X6_BK + 8 * (a_oct ^ ((a_row >> 3) & 1));
+    const int b_off = b_row * X6_BK + 8 * (b_oct ^ ((b_row >> 3) & 1));
+    float ra[8], rb[8];
+    auto fetch = [&](int step) {
+        const int kb = d.kb_inner ? step % d.kb_count : step / ksteps_per_kb;
+        const int k0 = (d.kb_inner ? step / d.kb_count : step - kb * ksteps_per_kb) * X6_BK;
+        if (k0 + X6_BK <= d.K) {         // wave-uniform
+            la.template load8<true>(arow, z, kb, k0 + 8 * a_oct, ra);
+            lb.template load8<true>(brow, z, kb, k0 + 8 * b_oct, rb);
+        } else {
+            la.template load8<false>(arow, z, kb, k0 + 8 * a_oct, ra);
+            lb.template load8<false>(brow, z, kb, k0 + 8 * b_oct, rb);
+        }
+    };
+    auto stash = [&](int buf) {
+        bf16x8 t1, t2, t3;
+        split8x3(ra, t1, t2, t3);
+        *reinterpret_cast<bf16x8*>(img(buf, 0) + a_off) = t1;
+        *reinterpret_cast<bf16x8*>(img(buf, 1) + a_off) = t2;
+        *reinterpret_cast<bf16x8*>(img(buf, 2) + a_off) = t3;
+        split8x3(rb, t1, t2, t3);
+        *reinterpret_cast<bf16x8*>(img(buf, 3) + b_off) = t1;
+        *reinterpret_cast<bf16x8*>(img(buf, 4) + b_off) = t2;
+        *reinterpret_cast<bf16x8*>(img(buf, 5) + b_off) = t3;
+    };
+    const int kh = lane >> 5, l31 = lane & 31;
+    auto mma = [&](int buf) {
+        bf16x8 a1[2], a2[2], a3[2], b1[2], b2[2], b3[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int ar = wm * 64 + t * 32 + l31, br = wn * 64 + t * 32 + l31;      // (row >> 3) & 1 == (l31 >> 3) & 1
+            const int ao = ar * X6_BK + 8 * (kh ^ ((l31 >> 3) & 1)), bo = br * X6_BK + 8 * (kh ^ ((l31 >> 3) & 1));
+            a1[t] = *reinterpret_cast<const bf16x8*>(img(buf, 0) + ao);
+            a2[t] = *reinterpret_cast<const bf16x8*>(img(buf, 1) + ao);
+            a3[t] = *reinterpret_cast<const bf16x8*>(img(buf, 2) + ao);
+            b1[t] = *reinterpret_cast<const bf16x8*>(img(buf, 3) + bo);
+            b2[t] = *reinterpret_cast<const bf16x8*>(img(buf, 4) + bo);
+            b3[t] = *reinterpret_cast<const bf16x8*>(img(buf, 5) + bo);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {       // smallest terms first
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[i], b1[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b3[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[i], b2[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[i], b1[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b2[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b1[j], acc[i][j], 0, 0, 0);
+            }
+    };
+
+    if (s_begin < s_end) {
+        fetch(s_begin);
+        stash(0);
+        if (s_begin + 1 < s_end) fetch(s_begin + 1);
+        __syncthreads();
+        int buf = 0;
+        for (int s = s_begin; s < s_end; ++s) {
+            if (s + 1 < s_end) stash(buf ^ 1);          // step s + 1 (registers) -> the other buffer (its readers passed the last barrier)
+            if (s + 2 < s_end) fetch(s + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(buf);
+            __syncthreads();
+            buf ^= 1;
+        }
+    } else if (!first_split) {
+        return;
+    }
+    epi_select_slice(epi, (int)blockIdx.y);
+
+    // D layout of a 32x32 block: lane -> column l31, register r -> row (r & 3) + 8 (r >> 2) + 4 (lane >> 5); the two column blocks
+    // exchange halves so that one register is ONE row across the wave's 64 columns (256-byte stores)
+    const int n = n0 + wn * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[i][0][r]), __float_as_uint(acc[i][1][r]), false, false);
+            const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2);
+            if (n < d.N) {
+                if (m < d.M) epi(z, m, n, __uint_as_float(sw[0]), first_split);
+                if (m + 4 < d.M) epi(z, m + 4, n, __uint_as_float(sw[1]), first_split);
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Large-tile variant for the big contractions (3x3 convs, FC1, theta^T phi): 256x256x32 tile, 512 threads =
 // 8 waves as 2(M) x 4(N), wave tile 128x64 = 4x2 MFMA blocks (128 accumulator registers).  Against the 128x128
 // kernel every staged operand element feeds twice the MFMAs (LDS write traffic per flop halves; ds_write_b128
@@ -1074,13 +1214,16 @@ static inline int32_t launch_gemm_prec(int M, int N, int K, int kb_count, int ba
         GemmDims d6;
         d6.M = M; d6.N = N; d6.K = K; d6.kb_count = kb_count < 1 ? 1 : kb_count;
         d6.kb_inner = kb_inner ? 1 : 0;
-        d6.ksteps_total = d6.kb_count * cdiv(K, XB_BK);
+        static const bool x6_v1 = []() { const char* e = getenv("ARFE_X6_V1"); return e && e[0] == '1'; }();
+        const int bk6 = x6_v1 ? XB_BK : X6_BK;
+        d6.ksteps_total = d6.kb_count * cdiv(K, bk6);
         if (splitk < 1) splitk = 1;
         if (splitk > d6.ksteps_total && d6.ksteps_total > 0) splitk = d6.ksteps_total;
         d6.splitk = splitk;
         d6.tiles_m = cdiv(M, GEMM_BM); d6.tiles_n = cdiv(N, GEMM_BN);
         dim3 grid6(d6.tiles_m * d6.tiles_n, splitk, batch);
-        hipLaunchKernelGGL((gemm_bf16x6_kernel<LA, LB, EPI>), grid6, dim3(256), 0, stream, d6, la, lb, epi);
+        if (x6_v1) hipLaunchKernelGGL((gemm_bf16x6_kernel<LA, LB, EPI>), grid6, dim3(256), 0, stream, d6, la, lb, epi);
+        else hipLaunchKernelGGL((gemm_bf16x6v2_kernel<LA, LB, EPI>), grid6, dim3(256), X6_LDS_BYTES, stream, d6, la, lb, epi);
         ARFE_CHECK_LAUNCH();
         return ARFE_OK;
     }
