@@ -621,6 +621,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x6v2_kernel(GemmDims d, LA la
             }
     };
 
+#if defined(ARFE_PROBES) && defined(ARFE_CLOCK_PROBE)
+    const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     if (s_begin < s_end) {
         fetch(s_begin);
         stash(0);
@@ -639,6 +642,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x6v2_kernel(GemmDims d, LA la
         return;
     }
     epi_select_slice(epi, (int)blockIdx.y);
+#if defined(ARFE_PROBES) && defined(ARFE_CLOCK_PROBE)
+    if (tid == 0 && (blockIdx.x % 331) == 0 && blockIdx.z == 0) {        // in-kernel clock and main-loop cycles (tools/probe/nl_clock.py)
+        const unsigned long long dt = __builtin_amdgcn_s_memtime() - clk_t0, dr = __builtin_amdgcn_s_memrealtime() - clk_r0;
+        printf("x6 clk wg %d: %llu core cycles in %llu x 10 ns -> %.0f MHz\n", (int)blockIdx.x, dt, dr, dr ? 100.0 * (double)dt / (double)dr : 0.0);
+    }
+#endif
 
     // D layout of a 32x32 block: lane -> column l31, register r -> row (r & 3) + 8 (r >> 2) + 4 (lane >> 5); the two column blocks
     // exchange halves so that one register is ONE row across the wave's 64 columns (256-byte stores)
