@@ -29,7 +29,8 @@ constexpr int CS_BN = 224, CS_HALO = 8, CS_ROWS = CS_BN + 2 * CS_HALO;      // 2
 #define ARFE_CS_BLD 40
 #endif
 constexpr int CS_BLD = ARFE_CS_BLD;                                         // B image: 80-byte rows (shifted reads: no swizzle)
-constexpr int CS_ZROWS = 7;                                                 // zero rows behind the image: one per column block
+constexpr int CS_ZROWS = 8;                                                 // zero rows behind the image: one per column block, + 1: a tap that
+                                                                            // looks right reads (never uses) one row past block 6
 constexpr int CS_A_IMG = XL_BM * XS_LD;                                     // A image (swizzled 64-byte rows), elements
 constexpr int CS_B_IMG = (CS_ROWS + CS_ZROWS) * CS_BLD;
 constexpr int CS_LDS_BYTES = (2 * 2 * CS_A_IMG + 2 * 2 * CS_B_IMG) * 2;     // 2 buffers x (hi, lo) of each operand
