@@ -1370,3 +1370,30 @@ def test_rccl_one_rank_reducer_smoke():
         pytest.skip('no RCCL bootstrap here: ' + out.stdout[-300:])
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert 'avg op True' in out.stdout
+
+
+def test_bench_prints_one_json_line_with_the_contract_fields():
+    """bench.py's contract with the driver: ONE JSON line on stdout with the metric of BASELINE.json, the whole-job value, the
+    `roofline` object of the dominant kernel (HIP-event launch time inside the timed region) and the stage break-down; the
+    first-generation switches (ARFE_WGRAD_ROWS=0, ARFE_X6_V1=1: fresh process, read once) must produce a step as well."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    for extra in ({}, {'ARFE_WGRAD_ROWS': '0', 'ARFE_X6_V1': '1'}):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '2', '--no-cpu-baseline',
+                              '--no-fp16-leg'], env=dict(os.environ, **extra), cwd=ROOT, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+        assert len(lines) == 1, lines
+        d = json.loads(lines[0])
+        assert d['metric'].startswith('imgs/s AR-FPN+AR-RFF') and d['unit'] == 'imgs/s' and d['n_gpus'] == 1
+        assert d['steps'] == 3 and d['warmup'] == 2 and d['higher_is_better'] is True and d['scaling'] == 'weak'
+        assert d['vs_baseline'] is None and d['data'] == 'synthetic' and 'workload' in d['config']
+        assert abs(d['value'] - 2 * 1e3 / d['ms_per_step']) <= 1e-2 * d['value']            # B = 2 images per step
+        r = d['roofline']
+        assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and r['peak'] == 2500.0 and r['launches'] == 3 * 6
+        assert abs(r['frac'] - r['achieved'] / r['peak']) <= 1e-4 and 0.02 < r['frac'] < 0.33
+        assert set(d['stage_ms_per_step']) == {'arfpn_hbm_stages', 'nonlocal_fwd_bwd', 'conv3x3_fwd_and_dgrad'}
+        assert d['dist'] == {'backend': None, 'world_size': 1, 'launcher': False}
