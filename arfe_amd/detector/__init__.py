@@ -5,13 +5,13 @@ AR-RFF) build from the reference's config files and run forward_train end to end
 The hot path inside (necks, RoI extractor, bbox head) is the HIP library; nothing here replaces or shadows it."""
 from .anchors import AnchorGenerator, anchor_inside_flags, images_to_levels, unmap
 from .boxes import (AssignResult, BboxOverlaps2D, DeltaXYWHBBoxCoder, MaxIoUAssigner, RandomSampler, SamplingResult,
-                    batched_nms, bbox2delta, bbox_overlaps, delta2bbox, nms)
+                    batched_nms, bbox2delta, bbox2result, bbox_overlaps, delta2bbox, multiclass_nms, nms)
 from .losses import CrossEntropyLoss, L1Loss, SmoothL1Loss, accuracy
 from .resnet import Bottleneck, ResNet
 from .rpn_head import RPNHead
 from .two_stage import CascadeRCNN, FasterRCNN, TwoStageDetector, parse_losses, synthetic_batch
 
 __all__ = ['AnchorGenerator', 'anchor_inside_flags', 'images_to_levels', 'unmap', 'AssignResult', 'BboxOverlaps2D',
-           'DeltaXYWHBBoxCoder', 'MaxIoUAssigner', 'RandomSampler', 'SamplingResult', 'batched_nms', 'bbox2delta',
+           'DeltaXYWHBBoxCoder', 'MaxIoUAssigner', 'RandomSampler', 'SamplingResult', 'batched_nms', 'multiclass_nms', 'bbox2result', 'bbox2delta',
            'bbox_overlaps', 'delta2bbox', 'nms', 'CrossEntropyLoss', 'L1Loss', 'SmoothL1Loss', 'accuracy', 'Bottleneck',
            'ResNet', 'RPNHead', 'CascadeRCNN', 'FasterRCNN', 'TwoStageDetector', 'parse_losses', 'synthetic_batch']

@@ -301,3 +301,36 @@ def batched_nms(bboxes, scores, inds, nms_cfg, class_agnostic=False):
     # descending score, ties by ascending index: the order of the single pass (stable sort of the scores)
     keep = keep[scores[keep].sort(descending=True, stable=True)[1]]
     return torch.cat([bboxes[keep], scores[keep, None]], -1), keep
+
+
+def multiclass_nms(multi_bboxes, multi_scores, score_thr, nms_cfg, max_num=-1, score_factors=None):
+    """Test-time selection of detections (core/post_processing/bbox_nms.py:6-60): boxes [n, 4] or [n, 4 * classes], scores
+    [n, classes + 1] with the background LAST (ignored); every (box, class) pair above score_thr competes in a per-class hard NMS,
+    the best max_num survive.  -> ([k, 5] boxes with scores in descending score order, [k] zero-based labels)."""
+    num_classes = multi_scores.size(1) - 1
+    if multi_bboxes.shape[1] > 4:
+        bboxes = multi_bboxes.view(multi_scores.size(0), -1, 4)
+    else:
+        bboxes = multi_bboxes[:, None].expand(-1, num_classes, 4)
+    scores = multi_scores[:, :-1]
+    valid = scores > score_thr
+    bboxes = bboxes[valid]
+    if score_factors is not None:
+        scores = scores * score_factors[:, None]
+    scores = scores[valid]
+    labels = valid.nonzero(as_tuple=False)[:, 1]
+    if bboxes.numel() == 0:
+        return multi_bboxes.new_zeros((0, 5)), multi_bboxes.new_zeros((0, ), dtype=torch.long)
+    dets, keep = batched_nms(bboxes, scores, labels, nms_cfg)
+    if max_num > 0:
+        dets, keep = dets[:max_num], keep[:max_num]
+    return dets, labels[keep]
+
+
+def bbox2result(bboxes, labels, num_classes):
+    """[n, 5] detections + labels -> one float32 numpy array [n_c, 5] per class (core/bbox/transforms.py:73-89)."""
+    import numpy as np
+    if bboxes.shape[0] == 0:
+        return [np.zeros((0, 5), dtype=np.float32) for _ in range(num_classes)]
+    b, l = bboxes.detach().cpu().numpy(), labels.detach().cpu().numpy()
+    return [b[l == i, :] for i in range(num_classes)]

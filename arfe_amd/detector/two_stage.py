@@ -73,9 +73,33 @@ class TwoStageDetector(nn.Module):
                                                   gt_masks, **kwargs))
         return losses
 
+    # ---- test time (detectors/test_mixins.py:27-30, two_stage.py:236-330, base.py:100-135; no augmentation, no masks) ----
+    def simple_test_rpn(self, x, img_metas):
+        return self.rpn_head.get_bboxes(*self.rpn_head(x), img_metas)
+
+    @torch.no_grad()
+    def simple_test(self, img, img_metas, proposals=None, rescale=False):
+        """one image [1, 3, H, W] -> per-class [n_c, 5] detections (x1, y1, x2, y2, score)"""
+        x = self.extract_feat(img)
+        proposal_list = self.simple_test_rpn(x, img_metas) if proposals is None else proposals
+        return self.roi_head.simple_test(x, proposal_list, img_metas, rescale=rescale)
+
+    def forward_test(self, imgs, img_metas, **kwargs):
+        for var, name in ((imgs, 'imgs'), (img_metas, 'img_metas')):
+            if not isinstance(var, list):
+                raise TypeError(f'{name} must be a list, but got {type(var)}')
+        if len(imgs) != len(img_metas):
+            raise ValueError(f'num of augmentations ({len(imgs)}) != num of image meta ({len(img_metas)})')
+        if len(imgs) != 1:
+            raise NotImplementedError("test-time augmentation is outside the harness")
+        assert imgs[0].size(0) == 1, "the reference tests one image per GPU"
+        if 'proposals' in kwargs:
+            kwargs['proposals'] = kwargs['proposals'][0]
+        return self.simple_test(imgs[0], img_metas[0], **kwargs)
+
     def forward(self, img, img_metas, return_loss=True, **kwargs):
         if not return_loss:
-            raise NotImplementedError("inference post-processing (decode + multiclass NMS) is outside the harness")
+            return self.forward_test(img, img_metas, **kwargs)
         return self.forward_train(img, img_metas, **kwargs)
 
 

@@ -4,6 +4,7 @@ StandardRoIHead, with the reference's registry names, constructor arguments and 
 standard_roi_head.py:135-170 [intended body, :138-155], models/utils/additional.py:38-71)."""
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 from torch.nn.modules.utils import _pair
 
 from . import functional as Fn
@@ -195,6 +196,31 @@ class BBoxHead(nn.Module):
             else:
                 losses['loss_bbox'] = bbox_pred.sum() * 0
         return losses
+
+    def get_bboxes(self, rois, cls_score, bbox_pred, img_shape, scale_factor, rescale=False, cfg=None):
+        """Test-time decode (bbox_head.py:206-243): softmax scores (a list of stage scores is averaged first), every class's box
+        decoded from its roi and clipped to the image, optionally mapped back to the original image scale; with a test cfg the
+        per-class NMS follows (-> [k, 5] detections, [k] labels), without one the raw (boxes, scores)."""
+        from .detector.boxes import multiclass_nms
+        if isinstance(cls_score, list):
+            cls_score = sum(cls_score) / float(len(cls_score))
+        scores = F.softmax(cls_score.float(), dim=1) if cls_score is not None else None
+        if bbox_pred is not None:
+            bboxes = self.bbox_coder.decode(rois[:, 1:], bbox_pred.float(), max_shape=img_shape)
+        else:
+            # the reference "clamps" here with bboxes[:, [0, 2]].clamp_(...) - an in-place op on the COPY that advanced indexing
+            # returns, i.e. a no-op (bbox_head.py:222-225): the rois come back unclipped, and so they do here (pinned by the fixture)
+            bboxes = rois[:, 1:].clone()
+        if rescale:
+            if isinstance(scale_factor, float):
+                bboxes = bboxes / scale_factor
+            else:
+                sf = bboxes.new_tensor(scale_factor)
+                bboxes = (bboxes.view(bboxes.size(0), -1, 4) / sf).view(bboxes.size(0), -1)
+        if cfg is None:
+            return bboxes, scores
+        get = cfg.get if isinstance(cfg, dict) else (lambda k: getattr(cfg, k))
+        return multiclass_nms(bboxes, scores, get('score_thr'), get('nms'), get('max_per_img'))
 
     def regress_by_class(self, rois, label, bbox_pred, img_meta):
         """the box of the given class applied to each roi ([n, 4] or [n, 5] with the batch column kept); Cascade R-CNN."""
@@ -404,6 +430,21 @@ class StandardRoIHead(nn.Module):
         return bbox_results
 
 
+    # ---- test time (test_mixins.py:52-71, standard_roi_head.py:266-285; bbox branch only) ----
+    def simple_test_bboxes(self, x, img_metas, proposals, rcnn_test_cfg, rescale=False):
+        from .bbox import bbox2roi
+        rois = bbox2roi(proposals)
+        res = self._bbox_forward(x, rois)
+        return self.bbox_head.get_bboxes(rois, res['cls_score'], res['bbox_pred'], img_metas[0]['img_shape'],
+                                         img_metas[0]['scale_factor'], rescale=rescale, cfg=rcnn_test_cfg)
+
+    def simple_test(self, x, proposal_list, img_metas, proposals=None, rescale=False):
+        """one image (the reference's test loop runs samples_per_gpu = 1) -> per-class [n_c, 5] arrays"""
+        from .detector.boxes import bbox2result
+        det_bboxes, det_labels = self.simple_test_bboxes(x, img_metas, proposal_list, self.test_cfg, rescale=rescale)
+        return bbox2result(det_bboxes, det_labels, self.bbox_head.num_classes)
+
+
 @HEADS.register_module()
 class CascadeRoIHead(nn.Module):
     """The bbox feature path of the reference's CascadeRoIHead (cascade_roi_head.py:16-60 constructor / per-stage module
@@ -503,3 +544,23 @@ class CascadeRoIHead(nn.Module):
                     proposal_list = self.bbox_head[i].refine_bboxes(bbox_results['rois'], roi_labels,
                                                                     bbox_results['bbox_pred'], pos_is_gts, img_metas)
         return losses
+
+    def simple_test(self, x, proposal_list, img_metas, rescale=False):
+        """cascade_roi_head.py:285-349, bbox branch: every stage on the boxes the previous one regressed (by its best class,
+        background included - the regressors are class-agnostic in the cascade configs), the stages' class scores averaged, the
+        last stage's boxes decoded -> per-class [n_c, 5] arrays."""
+        from .bbox import bbox2roi
+        from .detector.boxes import bbox2result
+        rois = bbox2roi(proposal_list)
+        ms_scores, res = [], None
+        for i in range(self.num_stages):
+            res = self._bbox_forward(i, x, rois)
+            ms_scores.append(res['cls_score'].float())
+            if i < self.num_stages - 1:
+                label = res['cls_score'].argmax(dim=1)
+                label = cascade_refine_labels(self.bbox_head[i], label, res['cls_score'])
+                rois = self.bbox_head[i].regress_by_class(rois, label, res['bbox_pred'], img_metas[0])
+        cls_score = sum(ms_scores) / self.num_stages
+        det_bboxes, det_labels = self.bbox_head[-1].get_bboxes(rois, cls_score, res['bbox_pred'], img_metas[0]['img_shape'],
+                                                               img_metas[0]['scale_factor'], rescale=rescale, cfg=self.test_cfg)
+        return bbox2result(det_bboxes, det_labels, self.bbox_head[-1].num_classes)

@@ -405,6 +405,15 @@ def head_train_case():
         d[f'ht_{tag}_regress'] = one
         refined = head.refine_bboxes(rois, roi_labels, reg, [r.pos_is_gt for r in results], metas)
         d[f'ht_{tag}_refined0'], d[f'ht_{tag}_refined1'] = refined
+        # test-time decode without the NMS (cfg=None; the reference's multiclass_nms sits on its compiled NMS extension): plain,
+        # rescaled by a float and by a per-coordinate factor, and with a list of stage scores (Cascade's ensemble)
+        gb, gs = head.get_bboxes(rois, cls, reg, (64, 96, 3), 1.0)
+        d[f'ht_{tag}_gb_boxes'], d[f'ht_{tag}_gb_scores'] = gb, gs
+        d[f'ht_{tag}_gb_boxes_f'] = head.get_bboxes(rois, cls, reg, (64, 96, 3), 2.0, rescale=True)[0]
+        d[f'ht_{tag}_gb_boxes_v'] = head.get_bboxes(rois, cls, reg, (64, 96, 3), np.array([1.5, 1.25, 1.5, 1.25], dtype=np.float32),
+                                                    rescale=True)[0]
+        d[f'ht_{tag}_gb_scores_list'] = head.get_bboxes(rois, [cls, cls * 0.5, -cls], reg, (64, 96, 3), 1.0)[1]
+        d[f'ht_{tag}_gb_noreg'] = head.get_bboxes(rois, cls, None, (40, 50, 3), 1.0)[0]
     return d
 
 

@@ -246,6 +246,60 @@ def test_bbox_head_targets_loss_refine_match_reference(tag, agnostic):
         assert refined[i].shape == want.shape and (refined[i] - want).abs().max().item() <= 1e-5, i
 
 
+@pytest.mark.parametrize('tag,agnostic', [('cs', False), ('ag', True)])
+def test_bbox_head_get_bboxes_matches_reference(tag, agnostic):
+    """bbox_head.py:206-243 without the NMS (cfg=None): softmax scores, per-class decode + clip, rescale by a float or a
+    per-coordinate factor, a list of stage scores averaged (Cascade's ensemble), and the no-regression branch."""
+    import numpy as np
+    nc = 6
+    head = arfe_amd.build_head(dict(
+        type='MultiRoIsBBoxHead', in_channels=16, conv_out_channels=16, fc_out_channels=8, roi_feat_size=7, num_classes=nc,
+        reg_class_agnostic=agnostic,
+        bbox_coder=dict(type='DeltaXYWHBBoxCoder', target_means=[0., 0., 0., 0.], target_stds=[0.1, 0.1, 0.2, 0.2])))
+    rois, cls, reg = G['ht_rois'], G[f'ht_{tag}_cls'], G[f'ht_{tag}_reg']
+    boxes, scores = head.get_bboxes(rois, cls, reg, (64, 96, 3), 1.0)
+    assert (boxes - G[f'ht_{tag}_gb_boxes']).abs().max().item() <= 1e-5 and (scores - G[f'ht_{tag}_gb_scores']).abs().max().item() <= 1e-6
+    assert (head.get_bboxes(rois, cls, reg, (64, 96, 3), 2.0, rescale=True)[0] - G[f'ht_{tag}_gb_boxes_f']).abs().max().item() <= 1e-5
+    sf = np.array([1.5, 1.25, 1.5, 1.25], dtype=np.float32)
+    assert (head.get_bboxes(rois, cls, reg, (64, 96, 3), sf, rescale=True)[0] - G[f'ht_{tag}_gb_boxes_v']).abs().max().item() <= 1e-5
+    avg = head.get_bboxes(rois, [cls, cls * 0.5, -cls], reg, (64, 96, 3), 1.0)[1]
+    assert (avg - G[f'ht_{tag}_gb_scores_list']).abs().max().item() <= 1e-6
+    assert (head.get_bboxes(rois, cls, None, (40, 50, 3), 1.0)[0] - G[f'ht_{tag}_gb_noreg']).abs().max().item() <= 1e-6
+    # with a test cfg: the per-class NMS of multiclass_nms on those boxes / scores
+    dets, labels = head.get_bboxes(rois, cls, reg, (64, 96, 3), 1.0, cfg=dict(score_thr=0.05, nms=dict(type='nms', iou_thr=0.5), max_per_img=20))
+    want_d, want_l = D.multiclass_nms(boxes, scores, 0.05, dict(type='nms', iou_thr=0.5), 20)
+    assert torch.equal(dets, want_d) and torch.equal(labels, want_l) and dets.shape[0] <= 20
+
+
+def test_multiclass_nms_is_per_class_greedy_nms():
+    """core/post_processing/bbox_nms.py:6-60 (the reference's own NMS is a compiled extension: checked against the greedy loop):
+    (box, class) pairs above the threshold, background column ignored, greedy NMS inside each class, best max_num by score."""
+    g = torch.Generator().manual_seed(12)
+    n, nc = 120, 5
+    xy = torch.rand(n, 2, generator=g) * 70
+    wh = torch.rand(n, 2, generator=g) * 35 + 4
+    boxes = torch.cat([xy, xy + wh], 1)
+    scores = torch.softmax(torch.randn(n, nc + 1, generator=g) * 2.0, 1)
+    for per_class in (False, True):
+        mb = boxes if not per_class else (boxes[:, None, :] + torch.arange(nc).view(1, nc, 1) * 0.5).reshape(n, nc * 4)
+        dets, labels = D.multiclass_nms(mb, scores, 0.1, dict(type='nms', iou_thr=0.45), max_num=30)
+        want = []
+        for c in range(nc):
+            bc = mb if not per_class else mb.view(n, nc, 4)[:, c]
+            sel = torch.nonzero(scores[:, c] > 0.1, as_tuple=False).squeeze(1)
+            dc = torch.cat([bc[sel], scores[sel, c:c + 1]], 1)
+            want += [(float(dc[k, 4]), c, dc[k]) for k in _greedy_nms(dc, 0.45)]
+        want.sort(key=lambda t: -t[0])
+        want = want[:30]
+        assert dets.shape[0] == len(want) and labels.tolist() == [w[1] for w in want]
+        assert torch.allclose(dets, torch.stack([w[2] for w in want]))
+    res = D.bbox2result(dets, labels, nc)
+    assert len(res) == nc and sum(r.shape[0] for r in res) == dets.shape[0] and all(r.dtype.name == 'float32' for r in res)
+    assert all(r.shape == (0, 5) for r in D.bbox2result(torch.zeros(0, 5), torch.zeros(0, dtype=torch.long), nc))
+    e_d, e_l = D.multiclass_nms(boxes, scores * 0, 0.1, dict(type='nms', iou_thr=0.5))
+    assert e_d.shape == (0, 5) and e_l.shape == (0, )
+
+
 def test_cascade_refine_with_class_specific_regressor_and_background_targets():
     """with reg_class_agnostic=False the target label of a background RoI (== num_classes) must not reach
     regress_by_class's gather ([n, 4*num_classes] columns): background RoIs are refined by their best foreground class."""
@@ -396,3 +450,32 @@ def test_detector_forward_train_end_to_end(kind, depth):
     with torch.no_grad():
         outs = det.forward_dummy(img[:1])
     assert len(outs) == 2 + 2 * (1 if kind == 'FasterRCNN' else 3) and outs[-1].shape[0] == 1000
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kind', ['FasterRCNN', 'CascadeRCNN'])
+def test_detector_simple_test_end_to_end(kind):
+    """two_stage.py:236-330 / base.py:100-135: one image -> RPN proposals (test cfg) -> AR-RFF head(s) on the HIP library ->
+    decode -> per-class NMS -> per-class [n_c, 5] arrays; `forward(return_loss=False)` is the same call."""
+    import numpy as np
+    dev = torch.device('cuda:0')
+    det = _small_detector(kind, dev, 50).eval()
+    img, metas, _, _ = D.synthetic_batch(batch=1, height=256, width=384, max_gt=4, seed=2, device=dev)
+    res = det.simple_test(img, metas)
+    nc = (det.roi_head.bbox_head if kind == 'FasterRCNN' else det.roi_head.bbox_head[-1]).num_classes
+    assert len(res) == nc and all(isinstance(r, np.ndarray) and r.ndim == 2 and r.shape[1] == 5 for r in res)
+    n = sum(r.shape[0] for r in res)
+    assert n <= det.roi_head.test_cfg['max_per_img']
+    for r in res:
+        if r.shape[0]:
+            assert np.isfinite(r).all() and (r[:, 4] > det.roi_head.test_cfg['score_thr']).all() and (r[:, 4] <= 1.0).all()
+            assert (r[:, 0] >= 0).all() and (r[:, 2] <= 384).all() and (r[:, 1] >= 0).all() and (r[:, 3] <= 256).all()
+            assert (np.diff(r[:, 4]) <= 1e-7).all()                      # inside a class: descending score
+    again = det(img=[img], img_metas=[metas], return_loss=False)
+    assert len(again) == nc and all(np.array_equal(a, b) for a, b in zip(again, res))
+    with pytest.raises(NotImplementedError):
+        det(img=[img, img], img_metas=[metas, metas], return_loss=False)
+    # proposals handed in (two_stage.py:324-327): the RPN is skipped
+    props = [torch.tensor([[10., 20., 120., 140., 0.9], [50., 60., 300., 200., 0.8]], device=dev)]
+    res2 = det.simple_test(img, metas, proposals=props)
+    assert len(res2) == nc and sum(r.shape[0] for r in res2) <= 2 * nc
