@@ -95,6 +95,7 @@ def _ws(nbytes, device):
 
 
 _side_stream = {}
+_GATE_SEQ = os.environ.get('ARFE_GATE_SEQ', '1') != '0'         # 0: the two gating convs side by side on two streams (rounds 1-2)
 _GATE_FUSE = os.environ.get('ARFE_GATE_FUSE', '0') == '1'       # 1: gating convs in a row, fusion in the second one's epilogue (measured slower)
 _ONE_STREAM = os.environ.get('ARFE_ONE_STREAM', '0') == '1'      # measurement aid: everything on the current stream
 
@@ -742,6 +743,12 @@ def _rff_head_forward(x, params, packs, gate=None):
         # fusion launch) - measured 4.000 ms against 3.980 ms per step: the epilogue is a burst of all workgroups at once
         lw = conv3x3_fwd_op(base + 4 * C * 49, rs, R, C, pk_wh, b_wh, True)
         lh, z = conv3x3_fwd_fuse_op(base + 4 * 2 * C * 49, rs, R, C, pk_hh, b_hh, base, rs, lw)
+    elif _GATE_SEQ:
+        # the two gating convs one after the other on the current stream.  Side by side on two streams they took what two in a
+        # row take (each workgroup needs a CU's whole LDS, so the second launch only gets the CUs the first one leaves: 137 +
+        # 251 us against 2 x 131) and cost a join: 3.856 ms against 3.857 ms per step either way, one queue less to wait for
+        lw = conv3x3_fwd_op(base + 4 * C * 49, rs, R, C, pk_wh, b_wh, True)
+        lh = conv3x3_fwd_op(base + 4 * 2 * C * 49, rs, R, C, pk_hh, b_hh, True)
     else:
         # the two gating convs are independent: two 224-workgroup launches side by side pack the 256 CUs
         lh = on_side(x.device, lambda: conv3x3_fwd_op(base + 4 * 2 * C * 49, rs, R, C, pk_hh, b_hh, True))
