@@ -626,7 +626,7 @@ def test_conv3x3_bench_size_matches_torch_cpu(Fn, dev, R):
     assert relerr(db, br.grad) <= TOL_GRAD
 
 
-@pytest.mark.parametrize('R,C', [(32, 64), (96, 96), (64, 320), (50, 64), (5, 96)])
+@pytest.mark.parametrize('R,C', [(32, 64), (96, 96), (64, 320), (50, 64), (5, 96), (131, 64), (515, 32)])
 def test_conv3x3_stage_once_kernel_matches_torch_cpu(Fn, dev, R, C):
     """The stage-once conv kernel (conv_stage_once.hpp; taken when R*49 >= 224 and C is a multiple of 32, a ragged last
     tile included: R = 50 and R = 5): 224-pixel tiles cut RoIs, so the 8-pixel halo, the zero row of padding lanes, ReLU + bias, a
@@ -676,7 +676,7 @@ def test_conv3x3_fwd_fuse_equals_conv_then_fusion(Fn, dev, R, C):
     assert (z - z_ref).abs().max().item() <= 1e-6 * max(1.0, z_ref.abs().max().item())
 
 
-@pytest.mark.parametrize('R,C', [(64, 128), (65, 128), (200, 256)])
+@pytest.mark.parametrize('R,C', [(64, 128), (65, 128), (66, 128), (67, 128), (200, 256), (515, 128)])
 def test_conv3x3_wgrad_stage_once_kernel_matches_torch_cpu(Fn, dev, R, C):
     """The stage-once weight-gradient kernel (conv_wgrad_stage_once.hpp; C a multiple of 128, R >= 64): row slices of a
     single K-step, a last slice that ends inside a K-step (R = 65: 455 pixel rows), the row halo across slice and RoI
